@@ -102,6 +102,7 @@ def lib():
     L.orc_tracker_eval_weights.argtypes = [vp, vp, sz, vp, vp, vp, vp, sz, vp, P(C.c_int), vp, P(u64), P(u64)]
     L.orc_tracker_eval_weights.restype = sz
     L.orc_tracker_stage_times.argtypes = [vp, vp]
+    L.orc_tracker_set_matrix_override.argtypes = [vp, vp]
     _lib = L
     return L
 
@@ -313,8 +314,17 @@ class Tracker:
         lib().orc_tracker_stage_times(self.h, _ptr(s))
         return s
 
-    def eval_weights(self, particles, want_nn=False):
+    def eval_weights(self, particles, want_nn=False, mats=None):
+        """mats: optional (P,3,4) or (P,4,4) float32 matrices overriding toEigenMatrix(particle)"""
         p = np.ascontiguousarray(particles, PARTICLE_DTYPE)
+        m16 = None
+        if mats is not None:
+            mats = np.asarray(mats, np.float32)
+            m16 = np.zeros((len(p), 4, 4), np.float32)
+            m16[:, 3, 3] = 1.0
+            m16[:, :mats.shape[1], :] = mats
+            m16 = np.ascontiguousarray(m16)
+        lib().orc_tracker_set_matrix_override(self.h, _ptr(m16))
         P, M = len(p), self.M
         N = len(self._keep["input"])
         raw = np.zeros(P, np.float32)
@@ -327,6 +337,7 @@ class Tracker:
         sq, sp = C.c_uint64(), C.c_uint64()
         nc = lib().orc_tracker_eval_weights(self.h, _ptr(p), P, _ptr(raw), _ptr(nn_idx), _ptr(nn_d2), _ptr(crop), N,
                                             _ptr(bbox), C.byref(depth), _ptr(ob), C.byref(sq), C.byref(sp))
+        lib().orc_tracker_set_matrix_override(self.h, None)
         return dict(raw=raw, nn_idx=None if nn_idx is None else nn_idx.reshape(P, M),
                     nn_d2=None if nn_d2 is None else nn_d2.reshape(P, M), crop_idx=crop[:nc].copy(), bbox=bbox,
                     octree_depth=depth.value, octree_min=ob[:3].copy(), octree_max=ob[3:].copy(),

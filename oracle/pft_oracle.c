@@ -640,6 +640,7 @@ struct orc_tracker {
   orc_point_t* transed; /* transed_reference_vector_: P clouds of M points */
   size_t transed_cap;
   double stage[7];
+  const float* mat_override; /* tests: P row-major 4x4 matrices used instead of toEigenMatrix(p) */
 };
 
 orc_tracker_t* orc_tracker_create(const orc_config_t* c) {
@@ -693,6 +694,7 @@ int orc_tracker_set_particles(orc_tracker_t* t, const orc_particle_t* p, size_t 
 }
 
 double orc_tracker_fit_ratio(const orc_tracker_t* t) { return t->fit_ratio; }
+void orc_tracker_set_matrix_override(orc_tracker_t* t, const float* m16) { t->mat_override = m16; }
 void orc_tracker_stage_times(const orc_tracker_t* t, double s[7]) { memcpy(s, t->stage, sizeof(double) * 7); }
 
 static int n_threads(const orc_tracker_t* t) {
@@ -741,7 +743,10 @@ size_t orc_tracker_eval_weights(orc_tracker_t* t, const orc_particle_t* particle
   for (long i = 0; i < (long)P; i++) {
     float T[16];
     const orc_particle_t* p = &particles[i];
-    orc_get_transformation(p->x, p->y, p->z, p->roll, p->pitch, p->yaw, T);
+    if (t->mat_override)
+      memcpy(T, t->mat_override + 16 * (size_t)i, sizeof(T));
+    else
+      orc_get_transformation(p->x, p->y, p->z, p->roll, p->pitch, p->yaw, T);
     orc_transform_cloud(t->ref, M, T, t->transed + (size_t)i * M);
   }
   double t1 = omp_get_wtime();

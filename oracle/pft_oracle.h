@@ -123,6 +123,9 @@ void orc_tracker_get_result(const orc_tracker_t* t, orc_particle_t* out);
 size_t orc_tracker_get_particles(const orc_tracker_t* t, orc_particle_t* out, size_t cap);
 int orc_tracker_set_particles(orc_tracker_t* t, const orc_particle_t* p, size_t n);
 double orc_tracker_fit_ratio(const orc_tracker_t* t);
+/* tests only: use these P row-major 4x4 matrices instead of toEigenMatrix(particle) in eval_weights
+ * (isolates the float descent/coherence arithmetic from libm-vs-ocml sin/cos ulp differences) */
+void orc_tracker_set_matrix_override(orc_tracker_t* t, const float* m16);
 
 /* Stage hook: the deterministic chain A1-A7 of one weight() call on explicit particles.
  * Any output pointer may be NULL.

@@ -1,0 +1,927 @@
+// pft_api.hip -- the extern "C" boundary declared in include/pft.h: handle lifetime, HBM buffers,
+// the A12 schedule (ParticleFilterOMPTracker::computeTracking) as a chain of kernel launches on one
+// HIP stream, and the test / profiling hooks.  No CPU compute path exists here: every stage is a kernel.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "pft_internal.h"
+
+#define HIPCHK(t, call)                                                                       \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      (t)->err = std::string(#call) + ": " + hipGetErrorString(e_);                           \
+      return PFT_ERR_HIP;                                                                     \
+    }                                                                                         \
+  } while (0)
+
+struct EvPair {
+  hipEvent_t a, b;
+};
+
+struct pft_tracker {
+  pft_config cfg;
+  PftParams prm;
+  PftDev dev;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int num_cus = 256;
+  std::string err;
+
+  // buffers
+  pft_point_xyzrgba* d_ref_raw = nullptr;
+  float4 *d_ref_xyz = nullptr, *d_ref_hsv = nullptr;
+  uint32_t ref_cap = 0;
+  pft_point_xyzrgba* d_in_raw = nullptr;
+  float4* d_in_pts = nullptr;
+  uint32_t in_cap = 0, N = 0;
+  pft_particle* d_part[2] = {nullptr, nullptr};
+  int cur = 0;
+  float* d_mats = nullptr;
+  float* d_bbox_part = nullptr;
+  float* d_bbox6 = nullptr;
+  uint32_t* d_crop_counts = nullptr;
+  float4* d_crop_pts = nullptr;
+  int32_t* d_crop_idx = nullptr;
+  uint32_t* d_words = nullptr;
+  uint32_t max_words = 0;
+  float* d_centers = nullptr;
+  float4* d_leaf_pts = nullptr;
+  uint32_t *d_leaf_order = nullptr, *d_pt_node = nullptr, *d_pt_key = nullptr, *d_pt_tmp = nullptr,
+           *d_leaf_cursor = nullptr;
+  double* d_partial = nullptr;
+  int32_t* d_alias_a = nullptr;
+  double* d_alias_q = nullptr;
+  int32_t* d_alias_list = nullptr;
+  double* d_alias_pref = nullptr;
+  PftHeader* d_hdr = nullptr;
+  int32_t* d_nn_idx = nullptr;
+  float* d_nn_d2 = nullptr;
+  size_t nn_cap = 0;
+  // debug scratch
+  pft_particle* d_dbg_part = nullptr;
+  size_t dbg_part_cap = 0;
+  PftHeader* d_dbg_hdr = nullptr;
+  float* d_dbg_f = nullptr;
+  size_t dbg_f_cap = 0;
+  // dist binding
+  void *bound_bbox6 = nullptr, *bound_shard = nullptr, *bound_gathered = nullptr;
+
+  // state
+  bool has_ref = false, has_input = false, initialized = false, changed = false;
+  uint32_t resample_epoch = 0;
+  float trans[16];
+
+  // profiling
+  bool prof = false;
+  std::vector<EvPair> ev[PFT_K_COUNT];
+  std::vector<EvPair> ev_free;
+  double prof_ms[PFT_K_COUNT] = {0};
+  uint64_t prof_n[PFT_K_COUNT] = {0};
+};
+
+static const char* k_names[PFT_K_COUNT] = {"resample", "aabb", "crop", "octree", "likelihood", "population", "pack"};
+
+extern "C" const char* pft_kernel_name(int id) { return (id >= 0 && id < PFT_K_COUNT) ? k_names[id] : "?"; }
+
+extern "C" const char* pft_status_string(int s) {
+  switch (s) {
+    case PFT_OK: return "ok";
+    case PFT_ERR_INVALID_ARG: return "invalid argument";
+    case PFT_ERR_NO_INPUT: return "no input cloud";
+    case PFT_ERR_NO_REFERENCE: return "no reference cloud";
+    case PFT_ERR_NO_DEVICE: return "no usable HIP device (there is no CPU fallback)";
+    case PFT_ERR_HIP: return "HIP error";
+    case PFT_ERR_CAPACITY: return "capacity exceeded";
+    case PFT_ERR_STATE: return "invalid state";
+  }
+  return "unknown";
+}
+
+extern "C" void pft_config_default(pft_config* c) {
+  memset(c, 0, sizeof(*c));
+  c->abi_version = PFT_ABI_VERSION;
+  c->device_id = 0;
+  c->stream = nullptr;
+  c->particle_num = 400;
+  c->iteration_num = 2;
+  for (int k = 0; k < 6; k++) {
+    c->step_noise_cov[k] = 0.015 * 0.015;
+    c->initial_noise_cov[k] = 0.00001;
+    c->initial_noise_mean[k] = 0.0;
+  }
+  c->step_noise_cov[3] *= 40.0;
+  c->step_noise_cov[4] *= 40.0;
+  c->step_noise_cov[5] *= 40.0;
+  c->alpha = 15.0;
+  c->resample_likelihood_thr = 0.0;
+  c->max_distance = 0.1;
+  c->octree_resolution = 0.01;
+  c->distance_weight = 1.0;
+  c->hsv_weight = 0.1;
+  c->h_weight = 1.0;
+  c->s_weight = 1.0;
+  c->v_weight = 0.0;
+  c->hsv_pcl180_argorder = 1;
+  c->use_normal = 0;
+  c->seed = 1;
+  c->rank = 0;
+  c->world_size = 1;
+}
+
+// ---- host-side A1 / A0 helpers (toEigenMatrix / toState), float like PCL ----
+extern "C" void pft_to_matrix(const pft_particle* p, float m[16]) {
+  float A = cosf(p->yaw), B = sinf(p->yaw), C = cosf(p->pitch), D = sinf(p->pitch);
+  float E = cosf(p->roll), F = sinf(p->roll), DE = D * E, DF = D * F;
+  m[0] = A * C;  m[1] = A * DF - B * E;  m[2] = B * F + A * DE;  m[3] = p->x;
+  m[4] = B * C;  m[5] = A * E + B * DF;  m[6] = B * DE - A * F;  m[7] = p->y;
+  m[8] = -D;     m[9] = C * F;           m[10] = C * E;          m[11] = p->z;
+  m[12] = 0;     m[13] = 0;              m[14] = 0;              m[15] = 1;
+}
+
+extern "C" void pft_to_state(const float m[16], pft_particle* out) {
+  memset(out, 0, sizeof(*out));
+  out->x = m[3];
+  out->y = m[7];
+  out->z = m[11];
+  out->w = 1.0f;
+  out->roll = atan2f(m[9], m[10]);
+  out->pitch = asinf(-m[8]);
+  out->yaw = atan2f(m[4], m[0]);
+}
+
+// ---- profiling helpers ----
+struct ProfScope {
+  pft_tracker* t;
+  int id;
+  EvPair p;
+  bool on;
+  ProfScope(pft_tracker* t_, int id_) : t(t_), id(id_), on(t_->prof) {
+    if (!on) return;
+    if (!t->ev_free.empty()) {
+      p = t->ev_free.back();
+      t->ev_free.pop_back();
+    } else {
+      hipEventCreate(&p.a);
+      hipEventCreate(&p.b);
+    }
+    hipEventRecord(p.a, t->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    hipEventRecord(p.b, t->stream);
+    t->ev[id].push_back(p);
+  }
+};
+
+static void prof_collect(pft_tracker* t) {
+  hipStreamSynchronize(t->stream);
+  for (int k = 0; k < PFT_K_COUNT; k++) {
+    for (auto& p : t->ev[k]) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+        t->prof_ms[k] += ms;
+        t->prof_n[k] += 1;
+      }
+      t->ev_free.push_back(p);
+    }
+    t->ev[k].clear();
+  }
+}
+
+extern "C" int pft_profile_enable(pft_tracker* t, int on) {
+  if (!t) return PFT_ERR_INVALID_ARG;
+  if (!on && t->prof) prof_collect(t);
+  t->prof = on != 0;
+  return PFT_OK;
+}
+extern "C" int pft_profile_get(pft_tracker* t, int id, double* total_ms, uint64_t* launches) {
+  if (!t || id < 0 || id >= PFT_K_COUNT) return PFT_ERR_INVALID_ARG;
+  prof_collect(t);
+  if (total_ms) *total_ms = t->prof_ms[id];
+  if (launches) *launches = t->prof_n[id];
+  return PFT_OK;
+}
+extern "C" int pft_profile_reset(pft_tracker* t) {
+  if (!t) return PFT_ERR_INVALID_ARG;
+  prof_collect(t);
+  for (int k = 0; k < PFT_K_COUNT; k++) {
+    t->prof_ms[k] = 0;
+    t->prof_n[k] = 0;
+  }
+  return PFT_OK;
+}
+
+// ---- allocation ----
+template <typename T>
+static hipError_t dalloc(T** p, size_t n) {
+  return hipMalloc(reinterpret_cast<void**>(p), (n ? n : 1) * sizeof(T));
+}
+template <typename T>
+static void dfree(T*& p) {
+  if (p) hipFree(p);
+  p = nullptr;
+}
+
+static void sync_dev(pft_tracker* t) {
+  PftDev& d = t->dev;
+  d.ref_xyz = t->d_ref_xyz;
+  d.ref_hsv = t->d_ref_hsv;
+  d.in_pts = t->d_in_pts;
+  d.N = t->N;
+  d.part_cur = t->d_part[t->cur];
+  d.part_all = t->bound_gathered ? static_cast<pft_particle*>(t->bound_gathered) : t->d_part[t->cur];
+  d.mats = t->d_mats;
+  d.bbox_part = t->d_bbox_part;
+  d.bbox_grid = (uint32_t)t->num_cus;
+  d.bbox6 = t->bound_bbox6 ? static_cast<float*>(t->bound_bbox6) : t->d_bbox6;
+  d.crop_counts = t->d_crop_counts;
+  d.crop_pts = t->d_crop_pts;
+  d.crop_idx = t->d_crop_idx;
+  d.words = t->d_words;
+  d.max_words = t->max_words;
+  d.centers = t->d_centers;
+  d.leaf_pts = t->d_leaf_pts;
+  d.leaf_order = t->d_leaf_order;
+  d.pt_node = t->d_pt_node;
+  d.pt_key = t->d_pt_key;
+  d.pt_tmp = t->d_pt_tmp;
+  d.leaf_cursor = t->d_leaf_cursor;
+  d.partial = t->d_partial;
+  d.alias_a = t->d_alias_a;
+  d.alias_q = t->d_alias_q;
+  d.alias_list = t->d_alias_list;
+  d.alias_pref = t->d_alias_pref;
+  d.hdr = t->d_hdr;
+  d.nn_idx = t->d_nn_idx;
+  d.nn_d2 = t->d_nn_d2;
+}
+
+static int ensure_input_capacity(pft_tracker* t, uint32_t n) {
+  if (n <= t->in_cap) return PFT_OK;
+  if ((uint64_t)n * 8ull + 64ull >= (1ull << 24)) {
+    t->err = "input cloud too large for 24-bit octree child offsets";
+    return PFT_ERR_CAPACITY;
+  }
+  hipStreamSynchronize(t->stream);
+  dfree(t->d_in_raw); dfree(t->d_in_pts); dfree(t->d_crop_counts); dfree(t->d_crop_pts); dfree(t->d_crop_idx);
+  dfree(t->d_words); dfree(t->d_leaf_pts); dfree(t->d_leaf_order); dfree(t->d_pt_node); dfree(t->d_pt_key);
+  dfree(t->d_pt_tmp); dfree(t->d_leaf_cursor);
+  uint32_t cap = n;
+  t->max_words = cap * 8u + 64u;
+  HIPCHK(t, dalloc(&t->d_in_raw, cap));
+  HIPCHK(t, dalloc(&t->d_in_pts, cap));
+  HIPCHK(t, dalloc(&t->d_crop_counts, (size_t)(cap / 1024 + 2)));
+  HIPCHK(t, dalloc(&t->d_crop_pts, cap));
+  HIPCHK(t, dalloc(&t->d_crop_idx, cap));
+  HIPCHK(t, dalloc(&t->d_words, t->max_words));
+  HIPCHK(t, dalloc(&t->d_leaf_pts, cap));
+  HIPCHK(t, dalloc(&t->d_leaf_order, cap));
+  HIPCHK(t, dalloc(&t->d_pt_node, cap));
+  HIPCHK(t, dalloc(&t->d_pt_key, (size_t)cap * 3));
+  HIPCHK(t, dalloc(&t->d_pt_tmp, cap));
+  HIPCHK(t, dalloc(&t->d_leaf_cursor, cap));
+  t->in_cap = cap;
+  return PFT_OK;
+}
+
+extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
+  if (!cfg || !out) return PFT_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (cfg->abi_version != PFT_ABI_VERSION || cfg->particle_num <= 0 || cfg->iteration_num <= 0 ||
+      cfg->world_size <= 0 || cfg->rank < 0 || cfg->rank >= cfg->world_size || cfg->use_normal != 0 ||
+      cfg->particle_num % cfg->world_size != 0 || !(cfg->octree_resolution > 0))
+    return PFT_ERR_INVALID_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device_id >= ndev) return PFT_ERR_NO_DEVICE;
+  if (hipSetDevice(cfg->device_id) != hipSuccess) return PFT_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device_id) != hipSuccess) return PFT_ERR_NO_DEVICE;
+
+  pft_tracker* t = new pft_tracker();
+  t->cfg = *cfg;
+  t->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (cfg->stream) {
+    t->stream = static_cast<hipStream_t>(cfg->stream);
+  } else {
+    if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete t;
+      return PFT_ERR_HIP;
+    }
+    t->own_stream = true;
+  }
+  for (int i = 0; i < 16; i++) t->trans[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+
+  PftParams& p = t->prm;
+  memset(&p, 0, sizeof(p));
+  p.alpha = cfg->alpha;
+  p.maxd2 = cfg->max_distance * cfg->max_distance;
+  p.res = cfg->octree_resolution;
+  p.dist_w = cfg->distance_weight;
+  p.hsv_w = cfg->hsv_weight;
+  p.h_w = (float)cfg->h_weight;
+  p.s_w = (float)cfg->s_weight;
+  p.v_w = (float)cfg->v_weight;
+  p.hsv_argorder = cfg->hsv_pcl180_argorder;
+  for (int k = 0; k < 6; k++) {
+    p.step_sigma[k] = sqrt(cfg->step_noise_cov[k]);
+    p.init_sigma[k] = sqrt(cfg->initial_noise_cov[k]);
+    p.init_mean[k] = cfg->initial_noise_mean[k];
+  }
+  p.seed_lo = (uint32_t)cfg->seed;
+  p.seed_hi = (uint32_t)(cfg->seed >> 32);
+  p.P_total = (uint32_t)cfg->particle_num;
+  p.P_local = p.P_total / (uint32_t)cfg->world_size;
+  p.id_offset = p.P_local * (uint32_t)cfg->rank;
+  p.M = 0;
+  p.nchunk = 1;
+
+  const size_t Pl = p.P_local, Pt = p.P_total;
+  hipError_t e = hipSuccess;
+  auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  A(dalloc(&t->d_part[0], Pt));  // sized P_total so part_all can alias a shard buffer when world_size == 1
+  A(dalloc(&t->d_part[1], Pt));
+  A(dalloc(&t->d_mats, Pl * 12));
+  A(dalloc(&t->d_bbox_part, (size_t)t->num_cus * 6));
+  A(dalloc(&t->d_bbox6, 8));
+  A(dalloc(&t->d_centers, (size_t)3 * (2u << PFT_TABLE_MAX_DEPTH)));
+  A(dalloc(&t->d_alias_a, Pt));
+  A(dalloc(&t->d_alias_q, Pt));
+  A(dalloc(&t->d_alias_list, 2 * Pt));
+  A(dalloc(&t->d_alias_pref, 2 * Pt));
+  A(dalloc(&t->d_hdr, 1));
+  A(dalloc(&t->d_dbg_hdr, 1));
+  if (e == hipSuccess) e = hipMemsetAsync(t->d_hdr, 0, sizeof(PftHeader), t->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(t->d_dbg_hdr, 0, sizeof(PftHeader), t->stream);
+  if (e != hipSuccess) {
+    pft_destroy(t);
+    return PFT_ERR_HIP;
+  }
+  if (cfg->max_input_points) {
+    int r = ensure_input_capacity(t, cfg->max_input_points);
+    if (r != PFT_OK) {
+      pft_destroy(t);
+      return r;
+    }
+  }
+  sync_dev(t);
+  *out = t;
+  return PFT_OK;
+}
+
+extern "C" void pft_destroy(pft_tracker* t) {
+  if (!t) return;
+  if (t->stream) hipStreamSynchronize(t->stream);
+  for (int k = 0; k < PFT_K_COUNT; k++)
+    for (auto& p : t->ev[k]) {
+      hipEventDestroy(p.a);
+      hipEventDestroy(p.b);
+    }
+  for (auto& p : t->ev_free) {
+    hipEventDestroy(p.a);
+    hipEventDestroy(p.b);
+  }
+  dfree(t->d_ref_raw); dfree(t->d_ref_xyz); dfree(t->d_ref_hsv);
+  dfree(t->d_in_raw); dfree(t->d_in_pts);
+  dfree(t->d_part[0]); dfree(t->d_part[1]); dfree(t->d_mats); dfree(t->d_bbox_part); dfree(t->d_bbox6);
+  dfree(t->d_crop_counts); dfree(t->d_crop_pts); dfree(t->d_crop_idx); dfree(t->d_words); dfree(t->d_centers);
+  dfree(t->d_leaf_pts); dfree(t->d_leaf_order); dfree(t->d_pt_node); dfree(t->d_pt_key); dfree(t->d_pt_tmp);
+  dfree(t->d_leaf_cursor); dfree(t->d_partial); dfree(t->d_alias_a); dfree(t->d_alias_q); dfree(t->d_alias_list);
+  dfree(t->d_alias_pref); dfree(t->d_hdr); dfree(t->d_nn_idx); dfree(t->d_nn_d2); dfree(t->d_dbg_part);
+  dfree(t->d_dbg_hdr); dfree(t->d_dbg_f);
+  if (t->own_stream && t->stream) hipStreamDestroy(t->stream);
+  delete t;
+}
+
+extern "C" const char* pft_last_error_string(const pft_tracker* t) { return t ? t->err.c_str() : "null handle"; }
+
+extern "C" int pft_synchronize(pft_tracker* t) {
+  if (!t) return PFT_ERR_INVALID_ARG;
+  HIPCHK(t, hipStreamSynchronize(t->stream));
+  return PFT_OK;
+}
+
+extern "C" int pft_set_reference(pft_tracker* t, const pft_point_xyzrgba* pts, size_t n) {
+  if (!t || (!pts && n)) return PFT_ERR_INVALID_ARG;
+  if (n > 0x7fffffffu) return PFT_ERR_CAPACITY;
+  if (n > t->ref_cap) {
+    hipStreamSynchronize(t->stream);
+    dfree(t->d_ref_raw); dfree(t->d_ref_xyz); dfree(t->d_ref_hsv); dfree(t->d_partial);
+    HIPCHK(t, dalloc(&t->d_ref_raw, n));
+    HIPCHK(t, dalloc(&t->d_ref_xyz, n));
+    HIPCHK(t, dalloc(&t->d_ref_hsv, n));
+    t->ref_cap = (uint32_t)n;
+  }
+  t->prm.M = (uint32_t)n;
+  t->prm.nchunk = (uint32_t)((n + PFT_REF_CHUNK - 1) / PFT_REF_CHUNK);
+  if (t->prm.nchunk == 0) t->prm.nchunk = 1;
+  dfree(t->d_partial);
+  HIPCHK(t, dalloc(&t->d_partial, (size_t)t->prm.P_local * t->prm.nchunk));
+  if (n) {
+    HIPCHK(t, hipMemcpyAsync(t->d_ref_raw, pts, n * sizeof(pft_point_xyzrgba), hipMemcpyHostToDevice, t->stream));
+    pftk_pack_reference(t->stream, t->d_ref_raw, (uint32_t)n, t->prm.hsv_argorder, t->d_ref_xyz, t->d_ref_hsv);
+    HIPCHK(t, hipStreamSynchronize(t->stream));
+  }
+  t->has_ref = true;
+  sync_dev(t);
+  return PFT_OK;
+}
+
+extern "C" int pft_set_trans(pft_tracker* t, const float m[16]) {
+  if (!t || !m) return PFT_ERR_INVALID_ARG;
+  memcpy(t->trans, m, sizeof(float) * 16);
+  return PFT_OK;
+}
+
+static int set_input_common(pft_tracker* t, const void* src, size_t n, bool device) {
+  if (!t || (!src && n)) return PFT_ERR_INVALID_ARG;
+  if (n > 0x7fffffffu) return PFT_ERR_CAPACITY;
+  int r = ensure_input_capacity(t, (uint32_t)n);
+  if (r != PFT_OK) return r;
+  t->N = (uint32_t)n;
+  if (n) {
+    const pft_point_xyzrgba* dsrc = static_cast<const pft_point_xyzrgba*>(src);
+    if (!device) {
+      HIPCHK(t, hipMemcpyAsync(t->d_in_raw, src, n * sizeof(pft_point_xyzrgba), hipMemcpyHostToDevice, t->stream));
+      dsrc = t->d_in_raw;
+    }
+    {
+      ProfScope ps(t, PFT_K_PACK);
+      pftk_pack_input(t->stream, dsrc, (uint32_t)n, t->d_in_pts);
+    }
+    if (!device) HIPCHK(t, hipStreamSynchronize(t->stream));  // the host buffer is only borrowed for this call
+  }
+  t->has_input = n > 0;
+  sync_dev(t);
+  return PFT_OK;
+}
+
+extern "C" int pft_set_input(pft_tracker* t, const pft_point_xyzrgba* pts, size_t n) {
+  return set_input_common(t, pts, n, false);
+}
+extern "C" int pft_set_input_device(pft_tracker* t, const void* device_pts, size_t n) {
+  return set_input_common(t, device_pts, n, true);
+}
+
+// ---- the stages ----
+static void stage_init_particles(pft_tracker* t) {
+  pft_particle rep;
+  pft_to_state(t->trans, &rep);
+  rep.weight = 1.0f / (float)t->prm.P_total;
+  sync_dev(t);
+  ProfScope ps(t, PFT_K_RESAMPLE);
+  pftk_init_particles(t->stream, t->prm, rep, t->d_part[t->cur], t->d_mats, t->d_hdr);
+  t->initialized = true;
+  t->changed = false;
+  t->resample_epoch = 0;
+}
+
+static void stage_resample(pft_tracker* t) {
+  sync_dev(t);
+  pft_particle* out = t->d_part[1 - t->cur];
+  {
+    ProfScope ps(t, PFT_K_RESAMPLE);
+    pftk_resample(t->stream, t->prm, t->dev, t->resample_epoch, out);
+  }
+  t->resample_epoch++;
+  t->cur = 1 - t->cur;
+  sync_dev(t);
+}
+
+// A2+A3 (fused; transformed clouds are never materialised)
+static void stage_aabb(pft_tracker* t, const PftDev& d, uint32_t np) {
+  ProfScope ps(t, PFT_K_AABB);
+  pftk_aabb(t->stream, t->prm, d, np);
+}
+// A4, A5, A6+A7
+static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32_t np, bool debug_nn) {
+  {
+    ProfScope ps(t, PFT_K_CROP);
+    pftk_crop(t->stream, t->prm, d);
+  }
+  {
+    ProfScope ps(t, PFT_K_OCTREE);
+    pftk_octree(t->stream, t->prm, d);
+  }
+  {
+    ProfScope ps(t, PFT_K_LIKELIHOOD);
+    pftk_likelihood(t->stream, t->prm, d, np, debug_nn, t->num_cus);
+  }
+}
+
+__global__ void k_copy_particles(const pft_particle* __restrict__ src, pft_particle* __restrict__ dst, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+static int check_ready(pft_tracker* t) {
+  if (!t) return PFT_ERR_INVALID_ARG;
+  if (!t->has_input || t->N == 0) return PFT_ERR_NO_INPUT;  // PCL: PCL_ERROR + early return
+  if (!t->has_ref) return PFT_ERR_NO_REFERENCE;
+  return PFT_OK;
+}
+
+extern "C" int pft_compute(pft_tracker* t) {
+  int r = check_ready(t);
+  if (r != PFT_OK) return r;
+  if (t->cfg.world_size != 1) {
+    t->err = "pft_compute on a sharded handle: drive the pft_dist_* phases instead";
+    return PFT_ERR_STATE;
+  }
+  if (!t->initialized) stage_init_particles(t);
+  for (int it = 0; it < t->cfg.iteration_num; it++) {
+    if (t->changed) stage_resample(t);
+    sync_dev(t);
+    stage_aabb(t, t->dev, t->prm.P_local);
+    stage_crop_octree_likelihood(t, t->dev, t->prm.P_local, false);
+    {
+      ProfScope ps(t, PFT_K_POPULATION);
+      pftk_finalize_raw(t->stream, t->prm, t->dev, t->prm.P_local, nullptr);
+      // weight() ends with normalizeWeight(); use_change_detector_ == false => changed_ = true => update()
+      pftk_population(t->stream, t->prm, t->dev, t->prm.P_total, 1, 1, 1);
+    }
+    t->changed = true;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    t->err = std::string("kernel launch: ") + hipGetErrorString(e);
+    return PFT_ERR_HIP;
+  }
+  return PFT_OK;
+}
+
+// ---- multi-GPU phases ----
+extern "C" int pft_dist_bind(pft_tracker* t, void* bbox6_dev, void* shard_dev, void* gathered_dev) {
+  if (!t || !bbox6_dev || !shard_dev || !gathered_dev) return PFT_ERR_INVALID_ARG;
+  t->bound_bbox6 = bbox6_dev;
+  t->bound_shard = shard_dev;
+  t->bound_gathered = gathered_dev;
+  sync_dev(t);
+  return PFT_OK;
+}
+
+extern "C" int pft_dist_begin_frame(pft_tracker* t) {
+  int r = check_ready(t);
+  if (r != PFT_OK) return r;
+  if (!t->bound_gathered) {
+    t->err = "pft_dist_bind not called";
+    return PFT_ERR_STATE;
+  }
+  if (!t->initialized) stage_init_particles(t);
+  return PFT_OK;
+}
+
+extern "C" int pft_dist_phase_a(pft_tracker* t, int iteration) {
+  (void)iteration;
+  int r = check_ready(t);
+  if (r != PFT_OK) return r;
+  if (!t->initialized) return PFT_ERR_STATE;
+  if (t->changed) stage_resample(t);
+  sync_dev(t);
+  stage_aabb(t, t->dev, t->prm.P_local);
+  return PFT_OK;
+}
+
+extern "C" int pft_dist_phase_b(pft_tracker* t) {
+  int r = check_ready(t);
+  if (r != PFT_OK) return r;
+  sync_dev(t);
+  stage_crop_octree_likelihood(t, t->dev, t->prm.P_local, false);
+  {
+    ProfScope ps(t, PFT_K_POPULATION);
+    pftk_finalize_raw(t->stream, t->prm, t->dev, t->prm.P_local, nullptr);
+    hipLaunchKernelGGL(k_copy_particles, dim3((t->prm.P_local + 255) / 256), dim3(256), 0, t->stream,
+                       t->d_part[t->cur], static_cast<pft_particle*>(t->bound_shard), t->prm.P_local);
+  }
+  return PFT_OK;
+}
+
+extern "C" int pft_dist_phase_c(pft_tracker* t) {
+  int r = check_ready(t);
+  if (r != PFT_OK) return r;
+  sync_dev(t);
+  {
+    ProfScope ps(t, PFT_K_POPULATION);
+    pftk_population(t->stream, t->prm, t->dev, t->prm.P_total, 1, 1, 1);
+  }
+  t->changed = true;
+  return PFT_OK;
+}
+
+// ---- accessors ----
+extern "C" int pft_get_result(pft_tracker* t, pft_particle* out) {
+  if (!t || !out) return PFT_ERR_INVALID_ARG;
+  HIPCHK(t, hipMemcpyAsync(out, &t->d_hdr->rep, sizeof(pft_particle), hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(t, hipStreamSynchronize(t->stream));
+  return PFT_OK;
+}
+
+extern "C" int pft_get_fit_ratio(pft_tracker* t, double* out) {
+  if (!t || !out) return PFT_ERR_INVALID_ARG;
+  HIPCHK(t, hipMemcpyAsync(out, &t->d_hdr->fit_ratio, sizeof(double), hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(t, hipStreamSynchronize(t->stream));
+  return PFT_OK;
+}
+
+extern "C" int pft_get_particles(pft_tracker* t, pft_particle* out, size_t cap, size_t* n) {
+  if (!t) return PFT_ERR_INVALID_ARG;
+  size_t P = t->initialized ? t->prm.P_total : 0;
+  if (n) *n = P;
+  if (!out || !P) return PFT_OK;
+  size_t c = cap < P ? cap : P;
+  sync_dev(t);
+  HIPCHK(t, hipMemcpyAsync(out, t->dev.part_all, c * sizeof(pft_particle), hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(t, hipStreamSynchronize(t->stream));
+  return PFT_OK;
+}
+
+extern "C" int pft_set_particles(pft_tracker* t, const pft_particle* p, size_t n) {
+  if (!t || !p || n != t->prm.P_local) return PFT_ERR_INVALID_ARG;
+  HIPCHK(t, hipMemcpyAsync(t->d_part[t->cur], p, n * sizeof(pft_particle), hipMemcpyHostToDevice, t->stream));
+  pftk_pose_to_matrix(t->stream, t->d_part[t->cur], (uint32_t)n, t->d_mats);
+  pft_particle rep;
+  pft_to_state(t->trans, &rep);
+  rep.weight = 1.0f / (float)t->prm.P_total;
+  HIPCHK(t, hipMemcpyAsync(&t->d_hdr->rep, &rep, sizeof(rep), hipMemcpyHostToDevice, t->stream));
+  HIPCHK(t, hipStreamSynchronize(t->stream));
+  t->initialized = true;
+  t->changed = false;
+  return PFT_OK;
+}
+
+// ---- test hooks ----
+static int ensure_dbg_part(pft_tracker* t, size_t n) {
+  if (n > t->dbg_part_cap) {
+    hipStreamSynchronize(t->stream);
+    dfree(t->d_dbg_part);
+    HIPCHK(t, dalloc(&t->d_dbg_part, n));
+    t->dbg_part_cap = n;
+  }
+  return PFT_OK;
+}
+static int ensure_dbg_f(pft_tracker* t, size_t n) {
+  if (n > t->dbg_f_cap) {
+    hipStreamSynchronize(t->stream);
+    dfree(t->d_dbg_f);
+    HIPCHK(t, dalloc(&t->d_dbg_f, n));
+    t->dbg_f_cap = n;
+  }
+  return PFT_OK;
+}
+
+extern "C" int pft_eval_weights(pft_tracker* t, const pft_particle* particles, size_t P, float* raw_w,
+                                int32_t* nn_idx, float* nn_d2) {
+  int r = check_ready(t);
+  if (r != PFT_OK) return r;
+  if (!particles || !P) return PFT_ERR_INVALID_ARG;
+  if (P > t->prm.P_local) return PFT_ERR_CAPACITY;
+  r = ensure_dbg_part(t, P);
+  if (r != PFT_OK) return r;
+  r = ensure_dbg_f(t, P);
+  if (r != PFT_OK) return r;
+  const bool want_nn = nn_idx || nn_d2;
+  const size_t pairs = P * (size_t)t->prm.M;
+  if (want_nn && pairs > t->nn_cap) {
+    hipStreamSynchronize(t->stream);
+    dfree(t->d_nn_idx);
+    dfree(t->d_nn_d2);
+    HIPCHK(t, dalloc(&t->d_nn_idx, pairs));
+    HIPCHK(t, dalloc(&t->d_nn_d2, pairs));
+    t->nn_cap = pairs;
+  }
+  sync_dev(t);
+  PftDev d = t->dev;
+  d.part_cur = t->d_dbg_part;
+  d.part_all = t->d_dbg_part;
+  d.bbox6 = t->d_bbox6;
+  HIPCHK(t, hipMemcpyAsync(t->d_dbg_part, particles, P * sizeof(pft_particle), hipMemcpyHostToDevice, t->stream));
+  HIPCHK(t, hipMemsetAsync(&t->d_hdr->stat_queries, 0, 2 * sizeof(unsigned long long), t->stream));
+  pftk_pose_to_matrix(t->stream, t->d_dbg_part, (uint32_t)P, t->d_mats);
+  stage_aabb(t, d, (uint32_t)P);
+  stage_crop_octree_likelihood(t, d, (uint32_t)P, want_nn);
+  pftk_finalize_raw(t->stream, t->prm, d, (uint32_t)P, t->d_dbg_f);
+  if (raw_w) HIPCHK(t, hipMemcpyAsync(raw_w, t->d_dbg_f, P * sizeof(float), hipMemcpyDeviceToHost, t->stream));
+  if (nn_idx) HIPCHK(t, hipMemcpyAsync(nn_idx, t->d_nn_idx, pairs * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+  if (nn_d2) HIPCHK(t, hipMemcpyAsync(nn_d2, t->d_nn_d2, pairs * sizeof(float), hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(t, hipStreamSynchronize(t->stream));
+  // the matrices of the live particles were overwritten: restore them
+  if (t->initialized) pftk_pose_to_matrix(t->stream, t->d_part[t->cur], t->prm.P_local, t->d_mats);
+  HIPCHK(t, hipGetLastError());
+  return PFT_OK;
+}
+
+static int read_hdr(pft_tracker* t, PftHeader* h) {
+  HIPCHK(t, hipMemcpyAsync(h, t->d_hdr, sizeof(PftHeader), hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(t, hipStreamSynchronize(t->stream));
+  return PFT_OK;
+}
+
+extern "C" int pft_debug_get_bbox(pft_tracker* t, float bbox[6]) {
+  if (!t || !bbox) return PFT_ERR_INVALID_ARG;
+  PftHeader h;
+  int r = read_hdr(t, &h);
+  if (r != PFT_OK) return r;
+  memcpy(bbox, h.bbox, sizeof(float) * 6);
+  return PFT_OK;
+}
+
+extern "C" int pft_debug_get_crop(pft_tracker* t, int32_t* idx, size_t cap, size_t* n) {
+  if (!t) return PFT_ERR_INVALID_ARG;
+  PftHeader h;
+  int r = read_hdr(t, &h);
+  if (r != PFT_OK) return r;
+  if (n) *n = h.n_crop;
+  size_t c = cap < h.n_crop ? cap : h.n_crop;
+  if (idx && c) {
+    HIPCHK(t, hipMemcpy(idx, t->d_crop_idx, c * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  return PFT_OK;
+}
+
+extern "C" int pft_debug_get_octree(pft_tracker* t, int32_t* depth, double mn[3], double mx[3], uint32_t* n_leaves,
+                                    uint32_t* n_nodes) {
+  if (!t) return PFT_ERR_INVALID_ARG;
+  PftHeader h;
+  int r = read_hdr(t, &h);
+  if (r != PFT_OK) return r;
+  if (h.error) {
+    t->err = "octree build error flag " + std::to_string(h.error);
+    return PFT_ERR_CAPACITY;
+  }
+  if (depth) *depth = h.depth;
+  if (mn) memcpy(mn, h.omin, sizeof(double) * 3);
+  if (mx) memcpy(mx, h.omax, sizeof(double) * 3);
+  if (n_leaves) *n_leaves = h.n_leaves;
+  if (n_nodes) *n_nodes = h.n_words;
+  return PFT_OK;
+}
+
+extern "C" int pft_debug_get_point_keys(pft_tracker* t, uint32_t* keys3, size_t cap_points) {
+  if (!t || !keys3) return PFT_ERR_INVALID_ARG;
+  PftHeader h;
+  int r = read_hdr(t, &h);
+  if (r != PFT_OK) return r;
+  size_t c = cap_points < h.n_crop ? cap_points : h.n_crop;
+  if (c) HIPCHK(t, hipMemcpy(keys3, t->d_pt_key, c * 3 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return PFT_OK;
+}
+
+extern "C" int pft_debug_get_scan_stats(pft_tracker* t, uint64_t* queries, uint64_t* scanned) {
+  if (!t) return PFT_ERR_INVALID_ARG;
+  PftHeader h;
+  int r = read_hdr(t, &h);
+  if (r != PFT_OK) return r;
+  if (queries) *queries = h.stat_queries;
+  if (scanned) *scanned = h.stat_scanned;
+  return PFT_OK;
+}
+
+// population stages on explicit arrays (temporary buffers; the live state is not touched)
+struct DbgPop {
+  pft_particle* part = nullptr;
+  int32_t* a = nullptr;
+  double* q = nullptr;
+  int32_t* list = nullptr;
+  double* pref = nullptr;
+  ~DbgPop() {
+    dfree(part); dfree(a); dfree(q); dfree(list); dfree(pref);
+  }
+};
+
+static int dbg_population(pft_tracker* t, std::vector<pft_particle>& host, int norm, int mean, int alias, DbgPop& b,
+                          PftHeader* hout) {
+  const size_t n = host.size();
+  HIPCHK(t, dalloc(&b.part, n));
+  HIPCHK(t, dalloc(&b.a, n));
+  HIPCHK(t, dalloc(&b.q, n));
+  HIPCHK(t, dalloc(&b.list, 2 * n));
+  HIPCHK(t, dalloc(&b.pref, 2 * n));
+  HIPCHK(t, hipMemcpyAsync(b.part, host.data(), n * sizeof(pft_particle), hipMemcpyHostToDevice, t->stream));
+  HIPCHK(t, hipMemsetAsync(t->d_dbg_hdr, 0, sizeof(PftHeader), t->stream));
+  sync_dev(t);
+  PftDev d = t->dev;
+  d.part_all = b.part;
+  d.alias_a = b.a;
+  d.alias_q = b.q;
+  d.alias_list = b.list;
+  d.alias_pref = b.pref;
+  d.hdr = t->d_dbg_hdr;
+  pftk_population(t->stream, t->prm, d, (uint32_t)n, norm, mean, alias);
+  HIPCHK(t, hipMemcpyAsync(host.data(), b.part, n * sizeof(pft_particle), hipMemcpyDeviceToHost, t->stream));
+  if (hout) HIPCHK(t, hipMemcpyAsync(hout, t->d_dbg_hdr, sizeof(PftHeader), hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(t, hipStreamSynchronize(t->stream));
+  HIPCHK(t, hipGetLastError());
+  return PFT_OK;
+}
+
+extern "C" int pft_debug_normalize(pft_tracker* t, float* w, size_t n, double* fit_ratio) {
+  if (!t || !w || !n) return PFT_ERR_INVALID_ARG;
+  std::vector<pft_particle> h(n);
+  memset(h.data(), 0, n * sizeof(pft_particle));
+  for (size_t i = 0; i < n; i++) h[i].weight = w[i];
+  DbgPop b;
+  PftHeader hd;
+  int r = dbg_population(t, h, 1, 0, 0, b, &hd);
+  if (r != PFT_OK) return r;
+  for (size_t i = 0; i < n; i++) w[i] = h[i].weight;
+  if (fit_ratio) *fit_ratio = hd.fit_ratio;
+  return PFT_OK;
+}
+
+extern "C" int pft_debug_alias(pft_tracker* t, const float* w, size_t n, int32_t* a, double* q) {
+  if (!t || !w || !n || !a || !q) return PFT_ERR_INVALID_ARG;
+  std::vector<pft_particle> h(n);
+  memset(h.data(), 0, n * sizeof(pft_particle));
+  for (size_t i = 0; i < n; i++) h[i].weight = w[i];
+  DbgPop b;
+  int r = dbg_population(t, h, 0, 0, 1, b, nullptr);
+  if (r != PFT_OK) return r;
+  HIPCHK(t, hipMemcpy(a, b.a, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIPCHK(t, hipMemcpy(q, b.q, n * sizeof(double), hipMemcpyDeviceToHost));
+  return PFT_OK;
+}
+
+extern "C" int pft_debug_weighted_mean(pft_tracker* t, const pft_particle* p, size_t n, pft_particle* out) {
+  if (!t || !p || !n || !out) return PFT_ERR_INVALID_ARG;
+  std::vector<pft_particle> h(p, p + n);
+  DbgPop b;
+  PftHeader hd;
+  int r = dbg_population(t, h, 0, 1, 0, b, &hd);
+  if (r != PFT_OK) return r;
+  *out = hd.rep;
+  return PFT_OK;
+}
+
+extern "C" int pft_debug_init_particles(pft_tracker* t, const pft_particle* rep, uint32_t id_offset, size_t n_local,
+                                        pft_particle* out) {
+  if (!t || !rep || !out || !n_local) return PFT_ERR_INVALID_ARG;
+  pft_particle* d = nullptr;
+  HIPCHK(t, dalloc(&d, n_local));
+  PftParams p = t->prm;
+  p.id_offset = id_offset;
+  p.P_local = (uint32_t)n_local;
+  pftk_init_particles(t->stream, p, *rep, d, nullptr, nullptr);
+  hipError_t e = hipMemcpyAsync(out, d, n_local * sizeof(pft_particle), hipMemcpyDeviceToHost, t->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+  hipFree(d);
+  HIPCHK(t, e);
+  return PFT_OK;
+}
+
+extern "C" int pft_debug_resample(pft_tracker* t, const pft_particle* old, size_t n_total, const int32_t* a,
+                                  const double* q, const pft_particle* rep, uint32_t epoch, uint32_t id_offset,
+                                  size_t n_local, pft_particle* out) {
+  if (!t || !old || !a || !q || !rep || !out || !n_total || !n_local) return PFT_ERR_INVALID_ARG;
+  pft_particle *d_old = nullptr, *d_out = nullptr;
+  int32_t* d_a = nullptr;
+  double* d_q = nullptr;
+  hipError_t e = dalloc(&d_old, n_total);
+  if (e == hipSuccess) e = dalloc(&d_out, n_local);
+  if (e == hipSuccess) e = dalloc(&d_a, n_total);
+  if (e == hipSuccess) e = dalloc(&d_q, n_total);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_old, old, n_total * sizeof(pft_particle), hipMemcpyHostToDevice, t->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_a, a, n_total * sizeof(int32_t), hipMemcpyHostToDevice, t->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_q, q, n_total * sizeof(double), hipMemcpyHostToDevice, t->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(t->d_dbg_hdr, 0, sizeof(PftHeader), t->stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(&t->d_dbg_hdr->rep, rep, sizeof(pft_particle), hipMemcpyHostToDevice, t->stream);
+  if (e == hipSuccess) {
+    PftParams p = t->prm;
+    p.id_offset = id_offset;
+    p.P_local = (uint32_t)n_local;
+    p.P_total = (uint32_t)n_total;
+    PftDev d = t->dev;
+    d.part_all = d_old;
+    d.alias_a = d_a;
+    d.alias_q = d_q;
+    d.hdr = t->d_dbg_hdr;
+    d.mats = nullptr;
+    pftk_resample(t->stream, p, d, epoch, d_out);
+    e = hipMemcpyAsync(out, d_out, n_local * sizeof(pft_particle), hipMemcpyDeviceToHost, t->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+  hipFree(d_old); hipFree(d_out); hipFree(d_a); hipFree(d_q);
+  HIPCHK(t, e);
+  return PFT_OK;
+}
+
+extern "C" int pft_debug_pose_to_matrix(pft_tracker* t, const pft_particle* p, size_t n, float* m12) {
+  if (!t || !p || !n || !m12) return PFT_ERR_INVALID_ARG;
+  pft_particle* d = nullptr;
+  float* dm = nullptr;
+  hipError_t e = dalloc(&d, n);
+  if (e == hipSuccess) e = dalloc(&dm, n * 12);
+  if (e == hipSuccess) e = hipMemcpyAsync(d, p, n * sizeof(pft_particle), hipMemcpyHostToDevice, t->stream);
+  if (e == hipSuccess) {
+    pftk_pose_to_matrix(t->stream, d, (uint32_t)n, dm);
+    e = hipMemcpyAsync(m12, dm, n * 12 * sizeof(float), hipMemcpyDeviceToHost, t->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+  hipFree(d); hipFree(dm);
+  HIPCHK(t, e);
+  return PFT_OK;
+}

@@ -1,0 +1,115 @@
+// pft_internal.h -- device-side data layout + kernel launch prototypes (gfx950 only).
+//
+// HBM layout of one tracker (all arrays allocated once, resident for the handle's lifetime):
+//   ref_xyz / ref_hsv   float4[M]   reference points {x,y,z,-} and precomputed {fh,fs,fv,-}   (A7b, once)
+//   in_pts              float4[N]   input cloud {x,y,z,rgba-bits}                              (per frame)
+//   part[2]             particle[P_local] double-buffered shard; part_all = all P (gathered)
+//   mats                float[12*P_local] row-major 3x4 per particle                           (A1)
+//   bbox_part           float[6*grid] per-workgroup AABB partials -> bbox6 {-min xyz, max xyz}  (A3)
+//   crop_pts            float4[N]   cropped points {x,y,z,h|s<<8|v<<16}, input order            (A4)
+//   words               u32[]       linearised octree: branch = mask | child_base<<8, levels contiguous,
+//                                   leaf = start offset into leaf_pts (+ one sentinel)          (A5)
+//   centers             float[3][2^(D+1)] per-level per-axis voxel-centre tables                 (A6)
+//   leaf_pts            float4[N]   cropped points in leaf order (insertion order inside a leaf)
+//   partial             double[P_local*nchunk] per (particle, reference chunk) likelihood sums   (A7)
+//   alias_a / alias_q   int[P] / double[P]                                                       (A9)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pft.h"
+
+#define PFT_MAX_DEPTH 30
+#define PFT_TABLE_MAX_DEPTH 10
+#define PFT_MAX_GROW 40
+#define PFT_REF_CHUNK 512        // reference points per likelihood work item
+#define PFT_BUILD_THREADS 1024
+#define PFT_LIK_THREADS 1024
+#define PFT_POP_THREADS 1024
+
+struct PftParams {  // immutable per handle, passed by value to kernels
+  double alpha;
+  double maxd2;          // max_distance * max_distance (double, as PCL compares)
+  double res;            // octree resolution
+  double dist_w, hsv_w;
+  float h_w, s_w, v_w;
+  int hsv_argorder;
+  double step_sigma[6], init_sigma[6], init_mean[6];
+  uint32_t seed_lo, seed_hi;
+  uint32_t P_total, P_local, id_offset;
+  uint32_t M, nchunk;
+};
+
+struct PftHeader {  // lives in HBM; written by kernels, read by later kernels (and by the host for debug)
+  float bbox[6];    // x_min,x_max,y_min,y_max,z_min,z_max
+  uint32_t n_crop;
+  uint32_t error;   // bit0: octree capacity exceeded, bit1: depth exceeded
+  double omin[3], omax[3];
+  int32_t depth;
+  int32_t use_table;
+  uint32_t n_words;   // words used incl. leaf level + sentinel
+  uint32_t n_leaves;
+  uint32_t leaf_start;  // index of first leaf word
+  uint32_t lvl_start[PFT_MAX_DEPTH + 3];
+  int32_t n_grow;
+  uint32_t grow_idx[PFT_MAX_GROW];
+  uint32_t grow_shift[PFT_MAX_GROW];  // bit a set: axis a min lowered
+  uint32_t grow_old_depth[PFT_MAX_GROW];
+  double grow_min[PFT_MAX_GROW + 1][3];  // [e] = min valid for epoch e
+  double fit_ratio;
+  pft_particle rep;
+  pft_particle motion;
+  unsigned long long stat_queries, stat_scanned;
+};
+
+struct PftDev {  // device pointers (host-side struct, passed by value)
+  const float4* ref_xyz;
+  const float4* ref_hsv;
+  const float4* in_pts;
+  uint32_t N;
+  pft_particle* part_cur;   // shard being evaluated
+  pft_particle* part_all;   // all P particles (== part_cur when world_size == 1)
+  float* mats;
+  float* bbox_part;
+  uint32_t bbox_grid;
+  float* bbox6;             // {-xmin,-ymin,-zmin,xmax,ymax,zmax}: max-reducible across ranks
+  uint32_t* crop_counts;
+  float4* crop_pts;
+  int32_t* crop_idx;
+  uint32_t* words;
+  uint32_t max_words;
+  float* centers;
+  float4* leaf_pts;
+  uint32_t* leaf_order;
+  uint32_t* pt_node;
+  uint32_t* pt_key;     // 3 per point
+  uint32_t* pt_tmp;
+  uint32_t* leaf_cursor;
+  double* partial;
+  int32_t* alias_a;
+  double* alias_q;
+  int32_t* alias_list;   // 2*P scratch: L list, H list
+  double* alias_pref;    // 2*P scratch: D, E prefix sums
+  PftHeader* hdr;
+  int32_t* nn_idx;      // debug only
+  float* nn_d2;
+};
+
+// launchers (pft_kernels.hip)
+void pftk_pack_reference(hipStream_t s, const pft_point_xyzrgba* d_pts, uint32_t n, int argorder, float4* xyz,
+                         float4* hsv);
+void pftk_pack_input(hipStream_t s, const pft_point_xyzrgba* d_pts, uint32_t n, float4* out);
+void pftk_init_particles(hipStream_t s, const PftParams& p, pft_particle rep, pft_particle* out, float* mats,
+                         PftHeader* hdr);
+void pftk_resample(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t epoch, pft_particle* out);
+void pftk_pose_to_matrix(hipStream_t s, const pft_particle* p, uint32_t n, float* mats);
+void pftk_aabb(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles);
+void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d);
+void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d);
+void pftk_likelihood(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, bool debug_nn,
+                     int num_cus);
+void pftk_finalize_raw(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles,
+                       float* raw_out /*nullable*/);
+void pftk_population(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n /*particles in part_all*/,
+                     int do_normalize, int do_mean, int do_alias);
+int pftk_max_lds_bytes();

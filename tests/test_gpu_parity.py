@@ -1,0 +1,320 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every stage of the HIP path, called through the
+C ABI (include/pft.h), against the CPU oracle on the same seeded inputs.
+
+Bars: integer / index results (crop set, octree keys and depth, approximate-NN index) bit-exact; float
+results that involve no transcendental (AABB, NN squared distance) bit-exact; sums and transcendentals
+within the tolerance written at each assert; weighted-mean pose within 1e-4 (BASELINE.json north_star).
+PARITY UNPINNED: the oracle restates PCL 1.8.0, which is not available here (oracle/pft_oracle.h).
+"""
+import numpy as np
+import pytest
+
+from pcl_tracking_amd import scene
+
+pytestmark = pytest.mark.gpu
+
+
+def ulp_diff(a, b):
+    a = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7FFFFFFF), a)
+    b = np.where(b < 0, -(b & 0x7FFFFFFF), b)
+    return np.abs(a - b)
+
+
+def particles_around(pose, n, seed, sig_t=0.015, sig_r=0.09):
+    rng = np.random.default_rng(seed)
+    p = np.zeros(n, scene.PARTICLE_DTYPE)
+    for k, name in enumerate(("x", "y", "z")):
+        p[name] = pose[k] + rng.normal(0, sig_t, n)
+    for k, name in enumerate(("roll", "pitch", "yaw")):
+        p[name] = pose[3 + k] + rng.normal(0, sig_r, n)
+    p["w"] = 1.0
+    p["weight"] = 1.0 / n
+    return p
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from pcl_tracking_amd import tracker
+
+    return tracker
+
+
+@pytest.fixture(scope="module")
+def data():
+    return dict(model=scene.make_model(2048), scene=scene.make_scene(50000), gt=scene.model_gt_pose())
+
+
+def make_pair(gpu, orc, model, cloud, P, seed=1, **cfg):
+    g = gpu.make_reference_tracker(particle_num=P, seed=seed)
+    o = orc.Tracker(orc.default_config(particle_num=P, seed=seed, threads=0, emulate_pcl_alloc=0, **cfg))
+    for t, ref, tr, inp in ((g, g.setReferenceCloud, g.setTrans, g.setInputCloud),
+                            (o, o.set_reference, o.set_trans, o.set_input)):
+        ref(model)
+        tr(scene.initial_trans())
+        inp(cloud)
+    return g, o
+
+
+# ---- A1 -------------------------------------------------------------------------------------------
+def test_pose_to_matrix(gpu, orc, data):
+    g = gpu.make_reference_tracker(particle_num=64)
+    p = particles_around(data["gt"], 4096, 3, 0.5, 2.0)
+    got = g.debugPoseToMatrix(p)
+    want = np.stack([orc.get_transformation(*[q[k] for k in ("x", "y", "z", "roll", "pitch", "yaw")])[:3] for q in p])
+    # sin/cos: double->float on the GPU vs glibc cosf/sinf on the CPU; products of two such factors
+    d = ulp_diff(got, want)
+    small = np.abs(want) < 1e-3  # ulp distance is meaningless next to cancellation in A*DF - B*E
+    assert d[~small].max() <= 4, d[~small].max()
+    np.testing.assert_allclose(got, want, atol=3e-7, rtol=0)
+    assert (d == 0).mean() > 0.9
+
+
+# ---- A0 / A11 RNG -----------------------------------------------------------------------------------
+def test_init_particles(gpu, orc):
+    g = gpu.make_reference_tracker(particle_num=1000, seed=77)
+    cfg = orc.default_config(particle_num=1000, seed=77)
+    rep = np.zeros(1, scene.PARTICLE_DTYPE)
+    rep["x"], rep["y"], rep["z"], rep["yaw"], rep["w"], rep["weight"] = 0.3, -0.2, 1.1, 0.7, 1.0, 1e-3
+    want = orc.init_particles(cfg, rep, 0, 1000)
+    got = g.debugInitParticles(rep, 0, 1000)
+    for k in ("x", "y", "z", "roll", "pitch", "yaw"):
+        # double log/sin/cos differ by <= 1 ulp(double) between glibc and ocml: invisible after the float cast
+        assert ulp_diff(got[k], want[k]).max() <= 1
+        assert (got[k] == want[k]).mean() > 0.999
+    np.testing.assert_array_equal(got["weight"], want["weight"])
+    np.testing.assert_array_equal(g.debugInitParticles(rep, 600, 400)["x"], got["x"][600:])
+
+
+def test_resample(gpu, orc, data):
+    P = 2048
+    g = gpu.make_reference_tracker(particle_num=P, seed=5)
+    cfg = orc.default_config(particle_num=P, seed=5)
+    old = particles_around(data["gt"], P, 11)
+    rng = np.random.default_rng(0)
+    w = rng.random(P).astype(np.float32) ** 4
+    w[rng.random(P) < 0.1] = 0
+    w /= w.sum()
+    old["weight"] = w
+    a, q = orc.gen_alias_table(w)
+    rep = old[:1].copy()
+    rep["x"] += 0.5
+    for epoch in (0, 3):
+        want = orc.resample(cfg, old, a, q, rep, epoch)
+        got = g.debugResample(old, a, q, rep, epoch)
+        assert got[0].tobytes() == rep[0].tobytes()
+        for k in ("x", "y", "z", "roll", "pitch", "yaw"):
+            assert ulp_diff(got[k], want[k]).max() <= 1
+            assert (got[k] == want[k]).mean() > 0.999
+        np.testing.assert_array_equal(got["weight"], want["weight"])
+    np.testing.assert_array_equal(g.debugResample(old, a, q, rep, 3, 512, 256)["yaw"], got["yaw"][512:768])
+
+
+# ---- A2-A7 ------------------------------------------------------------------------------------------
+def check_eval(gpu, orc, model, cloud, P, pose, seed, expect_empty=False):
+    g, o = make_pair(gpu, orc, model, cloud, P)
+    p = particles_around(pose, P, seed)
+    mats = g.debugPoseToMatrix(p)
+    G = g.evalWeights(p, want_nn=True)
+    O = o.eval_weights(p, want_nn=True, mats=mats)  # same matrices: everything downstream must be bit-exact
+    # A3: AABB (float min/max, no rounding freedom)
+    np.testing.assert_array_equal(G["bbox"], O["bbox"].astype(np.float32))
+    # A4: crop set and order
+    np.testing.assert_array_equal(G["crop_idx"], O["crop_idx"])
+    if expect_empty:
+        assert len(G["crop_idx"]) == 0
+        assert (G["raw"] == 0).all() and (O["raw"] == 0).all() and (G["nn_idx"] == -1).all()
+        return G, O
+    assert len(G["crop_idx"]) > 0
+    # A5: box replay (doubles) and keys
+    assert G["octree_depth"] == O["octree_depth"]
+    np.testing.assert_array_equal(G["octree_min"], O["octree_min"])
+    np.testing.assert_array_equal(G["octree_max"], O["octree_max"])
+    ot = orc.Octree(np.ascontiguousarray(cloud)[O["crop_idx"]])
+    np.testing.assert_array_equal(G["point_keys"], ot.point_keys())
+    assert G["n_leaves"] == ot.info()["leaves"]
+    # A6: approximate nearest neighbour: index and squared distance, every pair
+    np.testing.assert_array_equal(G["nn_idx"], O["nn_idx"])
+    np.testing.assert_array_equal(G["nn_d2"], O["nn_d2"])
+    assert G["scan_queries"] == O["scan_queries"] and G["scan_points"] == O["scan_points"]
+    # A7: per-particle sum of ~M doubles, reduced in a different order, then cast to float
+    d = ulp_diff(G["raw"], O["raw"])
+    assert d.max() <= 1, d.max()
+    assert (d == 0).mean() > 0.99
+    return G, O
+
+
+def test_eval_weights_scene(gpu, orc, data):
+    G, O = check_eval(gpu, orc, data["model"], data["scene"], 256, data["gt"], 21)
+    assert G["octree_depth"] >= 6 and len(G["crop_idx"]) > 1000
+    assert (O["raw"] < -100).all()
+
+
+def test_eval_weights_real_trig(gpu, orc, data):
+    """same chain with each side computing its own matrices (cosf/sinf vs double->float): 1-ulp
+    differences in a matrix entry may flip a few neighbours; weights stay within 1e-3 absolute"""
+    g, o = make_pair(gpu, orc, data["model"], data["scene"], 256)
+    p = particles_around(data["gt"], 256, 5)
+    G = g.evalWeights(p, want_nn=True)
+    O = o.eval_weights(p, want_nn=True)
+    np.testing.assert_array_equal(G["crop_idx"], O["crop_idx"])
+    assert (G["nn_idx"] == O["nn_idx"]).mean() > 0.9999
+    np.testing.assert_allclose(G["raw"], O["raw"], atol=1e-3, rtol=0)
+
+
+@pytest.mark.parametrize("M,N,P", [(1, 1, 1), (63, 500, 7), (65, 1025, 33), (513, 3000, 129), (2048, 307200, 64)])
+def test_eval_weights_ragged_sizes(gpu, orc, M, N, P):
+    model = scene.make_model(M, seed=M)
+    if N == 307200:
+        cloud = scene.make_scene(N, mode="organized")  # BASELINE config 3: no downsample, many points per leaf
+    elif N == 1:
+        cloud = np.zeros(1, scene.POINT_DTYPE)
+        cloud["x"], cloud["y"], cloud["z"], cloud["w"] = scene.model_gt_pose()[:3] + (1.0,)
+    else:
+        cloud = scene.make_scene(50000)[:N]
+    G, O = check_eval(gpu, orc, model, cloud, P, scene.model_gt_pose(), 100 + M)
+    if N == 307200:
+        assert G["scan_points"] > 2 * G["scan_queries"]
+
+
+def test_eval_weights_empty_crop(gpu, orc, data):
+    far = (5.0, 5.0, 5.0, 0, 0, 0)
+    check_eval(gpu, orc, data["model"], data["scene"], 64, far, 9, expect_empty=True)
+
+
+def test_eval_weights_nonfinite_input_points(gpu, orc, data):
+    cloud = data["scene"].copy()
+    cloud["x"][::97] = np.nan
+    cloud["z"][5::101] = np.inf
+    check_eval(gpu, orc, data["model"], cloud, 64, data["gt"], 2)
+
+
+def test_eval_weights_wide_spread_deep_tree(gpu, orc, data):
+    """particles spread over metres: big crop, deep octree, many box-growth steps"""
+    g, o = make_pair(gpu, orc, data["model"], data["scene"], 128)
+    p = particles_around(data["gt"], 128, 4, sig_t=0.6, sig_r=1.0)
+    mats = g.debugPoseToMatrix(p)
+    G = g.evalWeights(p, want_nn=True)
+    O = o.eval_weights(p, want_nn=True, mats=mats)
+    assert G["octree_depth"] == O["octree_depth"] >= 8
+    np.testing.assert_array_equal(G["crop_idx"], O["crop_idx"])
+    np.testing.assert_array_equal(G["nn_idx"], O["nn_idx"])
+    np.testing.assert_array_equal(G["nn_d2"], O["nn_d2"])
+    assert ulp_diff(G["raw"], O["raw"]).max() <= 1
+
+
+# ---- A8, A9, A10 --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 400, 1000, 8192, 65536])
+def test_normalize(gpu, orc, n):
+    g = gpu.make_reference_tracker(particle_num=64)
+    rng = np.random.default_rng(n)
+    raw = (-rng.random(n) * 2000).astype(np.float32)
+    raw[rng.random(n) < 0.05] = 0.0
+    want, fw = orc.normalize_weights(raw)
+    got, fg = g.debugNormalize(raw)
+    assert fw == fg
+    assert ulp_diff(got, want).max() <= 1  # exp() in double differs by <= 1 ulp(double) glibc vs ocml
+    assert (got == want).mean() > 0.99
+    for special in (np.zeros(n, np.float32), np.full(n, -3.0, np.float32)):
+        np.testing.assert_array_equal(g.debugNormalize(special)[0], orc.normalize_weights(special)[0])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 400, 1000, 8192, 65536])
+def test_alias_table(gpu, orc, n):
+    g = gpu.make_reference_tracker(particle_num=64)
+    rng = np.random.default_rng(n + 1)
+    cases = []
+    w = rng.random(n).astype(np.float32) ** 6
+    w[rng.random(n) < 0.15] = 0
+    cases.append(w / max(w.sum(), 1e-30))
+    cases.append(np.full(n, np.float32(1) / np.float32(n), np.float32))  # uniform (after an all-equal frame)
+    w = np.zeros(n, np.float32)
+    w[n // 2] = 1.0
+    cases.append(w)  # all mass on one particle
+    w = np.full(n, np.float32(1) / np.float32(n), np.float32)
+    w[: n // 2] *= np.float32(0.5)
+    cases.append(w)  # exact ties in q
+    for w in cases:
+        a_w, q_w = orc.gen_alias_table(w)
+        a_g, q_g = g.debugAlias(w)
+        # same Walker table: identical aliases, probabilities equal up to the rounding of prefix sums vs
+        # sequential updates
+        np.testing.assert_array_equal(a_g, a_w)
+        np.testing.assert_allclose(q_g, q_w, atol=1e-9 * max(1, n), rtol=0)
+
+
+def test_weighted_mean(gpu, orc, data):
+    g = gpu.make_reference_tracker(particle_num=64)
+    for n in (1, 400, 8192):
+        p = particles_around(data["gt"], n, n)
+        w = np.random.default_rng(n).random(n).astype(np.float32)
+        p["weight"] = w / w.sum()
+        want = orc.weighted_mean(p)
+        got = g.debugWeightedMean(p)
+        for k in ("x", "y", "z", "roll", "pitch", "yaw"):
+            # PCL accumulates sequentially in float, the kernel tree-reduces in double
+            assert abs(float(got[k]) - float(want[k])) < 2e-6 * max(1.0, abs(float(want[k])))
+        assert got["weight"] == want["weight"]
+
+
+# ---- A12: the whole tracker -------------------------------------------------------------------------------
+@pytest.mark.parametrize("P", [400, 8192])
+def test_compute_tracks_like_oracle(gpu, orc, data, P):
+    """identical frames + RNG seed: weighted-mean pose within 1e-4 of the CPU tracker (north_star)"""
+    g, o = make_pair(gpu, orc, data["model"], data["scene"], P, seed=3)
+    frames = 4 if P == 400 else 2
+    for f in range(frames):
+        g.compute()
+        assert o.compute() == 0
+        rg, ro = g.getResult(), o.get_result()
+        for k in ("x", "y", "z", "roll", "pitch", "yaw"):
+            assert abs(float(rg[k]) - float(ro[k])) < 1e-4, (f, k, rg, ro)
+        assert rg["weight"] == ro["weight"]
+        assert abs(g.getFitRatio() - o.fit_ratio()) < 1e-2
+    pg, po = g.getParticles(), o.get_particles()
+    assert len(pg) == len(po) == P
+    same = np.ones(P, bool)
+    for k in ("x", "y", "z", "roll", "pitch", "yaw"):
+        same &= np.abs(pg[k] - po[k]) < 1e-5
+    assert same.mean() > 0.995  # a weight-rounding flip may redirect a handful of alias draws
+    np.testing.assert_allclose(pg["weight"][same], po["weight"][same], rtol=1e-3, atol=1e-9)
+
+
+def test_compute_moving_sequence(gpu, orc, data):
+    g, o = make_pair(gpu, orc, data["model"], data["scene"], 400, seed=8)
+    for f in range(3):
+        cloud = scene.make_scene(20000, obj_pose=scene.advance_pose(scene.GT_POSE, 4 * f))
+        g.setInputCloud(cloud)
+        o.set_input(cloud)
+        g.compute()
+        o.compute()
+        rg, ro = g.getResult(), o.get_result()
+        for k in ("x", "y", "z", "roll", "pitch", "yaw"):
+            assert abs(float(rg[k]) - float(ro[k])) < 1e-4
+
+
+def test_error_behaviour(gpu):
+    from pcl_tracking_amd._lib import PftError
+
+    t = gpu.make_reference_tracker(particle_num=16)
+    t.setReferenceCloud(scene.make_model(64))
+    with pytest.raises(PftError) as e:
+        t.compute()  # no input cloud: PCL prints PCL_ERROR and returns; the ABI reports PFT_ERR_NO_INPUT
+    assert e.value.status == 2
+    t2 = gpu.make_reference_tracker(particle_num=16)
+    with pytest.raises(PftError) as e:
+        t2.setInputCloud(scene.make_scene(50000)[:100])
+        t2.compute()
+    assert e.value.status == 3
+
+
+def test_native_library_is_loaded(gpu):
+    """the GPU tests must run on the HIP extension, not on a fallback"""
+    import os
+
+    from pcl_tracking_amd import _lib
+
+    _lib.load()
+    with open("/proc/%d/maps" % os.getpid()) as f:
+        assert "libpft_hip.so" in f.read()
