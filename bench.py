@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the tracking hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A "step" is one tracked frame = one pft_compute(): iteration_num x [resample, weight, update] over one
+batch of synthetic input (BASELINE.json configs[1]: 2 048-point model vs 50 000-point cloud, 8 192
+particles per GPU, single frame looped, filter left running).  Inputs are resident in HBM when the
+timed region starts.  Rank 0 prints ONE JSON line.  value = P_total * N_points / t_frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+P_PER_GPU = 8192
+M_MODEL = 2048
+N_CLOUD = 50000
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--particles-per-gpu", type=int, default=P_PER_GPU)
+    ap.add_argument("--model-points", type=int, default=M_MODEL)
+    ap.add_argument("--cloud-points", type=int, default=N_CLOUD)
+    ap.add_argument("--organized", action="store_true", help="N = w*h depth image, no downsample (config 3)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(model, cloud, trans, P, threads):
+    """the oracle (CPU restatement of the PCL OMP path, PCL-structured: per-particle clouds materialised,
+    pointer octree rebuilt per iteration, per-query index-vector allocation) timed on the host cores.
+    Test infrastructure used here only as the reported baseline."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+
+    cfg = oracle.default_config(particle_num=P, threads=threads, emulate_pcl_alloc=1, seed=1)
+    tr = oracle.Tracker(cfg)
+    tr.set_reference(model)
+    tr.set_trans(trans)
+    tr.set_input(cloud)
+    tr.compute()  # warm-up frame (includes initParticles)
+    times = []
+    stages = None
+    for _ in range(max(1, ARGS.cpu_frames)):
+        t0 = time.perf_counter()
+        tr.compute()
+        times.append(time.perf_counter() - t0)
+        stages = tr.stage_times()
+    return min(times), sorted(times)[len(times) // 2], stages
+
+
+def main():
+    import numpy as np
+    import torch
+
+    from pcl_tracking_amd import scene
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if ARGS.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (ARGS.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    P_local = ARGS.particles_per_gpu
+    P_total = P_local * world
+    M, N = ARGS.model_points, ARGS.cloud_points
+    model = scene.make_model(M)
+    cloud = scene.make_scene(N, mode="organized" if ARGS.organized else "voxel")
+    trans = scene.initial_trans()
+    cloud_dev = torch.from_numpy(cloud.view(np.uint8).reshape(-1).copy()).to(dev)  # PCL 32-B layout in HBM
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if world == 1:
+        from pcl_tracking_amd import tracker
+
+        t = tracker.make_reference_tracker(particle_num=P_total, seed=1, device_id=local_rank)
+        t.setReferenceCloud(model)
+        t.setTrans(trans)
+
+        def step():
+            t.setInputCloudDevice(cloud_dev.data_ptr(), N, keepalive=cloud_dev)
+            t.compute()
+
+        trk = t
+    else:
+        from pcl_tracking_amd.dist import HipPhases, ShardedFilter
+
+        ph = HipPhases(P_total, rank, world, dev, seed=1)
+        ph.set_reference(model)
+        ph.set_trans(trans)
+        sf = ShardedFilter(ph)
+
+        def step():
+            ph.set_input_device(cloud_dev, N)
+            sf.compute()
+
+        trk = ph.t
+
+    for _ in range(ARGS.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(ARGS.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    ms_per_step = dt / ARGS.steps * 1e3
+
+    # ---- per-kernel durations: HIP events on the kernels' own stream, same loop again ----
+    trk.profileEnable(True)
+    trk.profileReset()
+    sync()
+    t1 = time.perf_counter()
+    for _ in range(ARGS.steps):
+        step()
+    sync()
+    dt_prof = time.perf_counter() - t1
+    prof = trk.profileGet()
+    trk.profileEnable(False)
+    lik_ms, lik_n = prof["likelihood"]
+    lik_avg_s = lik_ms / max(1, lik_n) * 1e-3
+
+    out = None
+    if rank == 0:
+        # mean leaf occupancy of the steady-state workload (counted on the device, outside the timed region)
+        pcur = trk.getParticles()[:P_local]
+        st = trk.evalWeights(pcur, want_nn=True)
+        kbar = st["scan_points"] / max(1, st["scan_queries"])
+        # algorithmic bytes: per pair-eval 16 B reference point + 16 B per candidate scanned
+        bytes_per_launch = P_local * M * 16.0 * (1.0 + kbar)
+        achieved = bytes_per_launch / lik_avg_s / 1e9 if lik_avg_s > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                tj = json.load(open(tf))
+                key = "P%d_M%d_N%d" % (P_local, M, N)
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        pips = P_total * N / (dt / ARGS.steps)
+        out = {
+            "metric": "particles x input-points / sec per frame (tracked frames/sec @8192 particles per GPU)",
+            "value": pips,
+            "unit": "particle-points/s",
+            "n_gpus": world,
+            "steps": ARGS.steps,
+            "warmup": ARGS.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: %d-pt model vs %d-pt %s cloud, %d particles/GPU, 2 iterations/frame, "
+                            "single frame looped" % (M, N, "organized" if ARGS.organized else "voxel-downsampled", P_local),
+                "particles_total": P_total, "model_points": M, "cloud_points": N, "iterations_per_frame": 2,
+                "parallelism": "particles sharded x%d" % world,
+            },
+            "frames_per_s": ARGS.steps / dt,
+            "pair_evals_per_s": 2.0 * P_total * M / (dt / ARGS.steps),
+            "cropped_points": int(len(st["crop_idx"])), "octree_depth": int(st["octree_depth"]),
+            "mean_leaf_occupancy": kbar,
+            "ms_per_step_with_events": dt_prof / ARGS.steps * 1e3,
+            "kernel_ms_per_frame": {k: round(v[0] / ARGS.steps, 5) for k, v in prof.items()},
+            "roofline": {
+                "bound": "hbm", "kernel": "k_likelihood", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": lik_avg_s * 1e6,
+                "launches": int(lik_n),
+            },
+        }
+        if world == 1 and not ARGS.no_cpu_baseline:
+            cores = os.cpu_count() or 1
+            tmin, tmed, stages = cpu_baseline(model, cloud, trans, P_total, cores)
+            out["cpu_baseline"] = {
+                "value": P_total * N / tmin, "unit": "particle-points/s", "cores": cores, "kind": "port",
+                "sample": "%d frames of the same workload (P=%d, M=%d, N=%d, 2 iterations) after 1 warm-up frame; "
+                          "min frame time %.3f s, median %.3f s" % (ARGS.cpu_frames, P_total, M, N, tmin, tmed),
+                "stage_seconds": {k: round(float(v), 4) for k, v in zip(
+                    ("transform", "bbox_crop", "octree", "coherence", "normalize", "resample", "update"), stages)},
+            }
+            out["speedup_vs_cpu"] = pips / out["cpu_baseline"]["value"]
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    ARGS = parse()
+    main()

@@ -138,6 +138,13 @@ int pft_debug_get_octree(pft_tracker* t, int32_t* depth, double min_xyz[3], doub
                          uint32_t* n_nodes);
 int pft_debug_get_point_keys(pft_tracker* t, uint32_t* keys3, size_t cap_points);
 int pft_debug_get_scan_stats(pft_tracker* t, uint64_t* queries, uint64_t* scanned_points);
+/* wall-clock stamps (100 MHz ticks) taken at phase boundaries inside the single-workgroup kernels of the
+ * last iteration: [0..15] octree build, [16..31] population */
+int pft_debug_get_ticks(pft_tracker* t, uint64_t* ticks32);
+/* descent statistics of the last pft_eval_weights call that asked for the NN arrays: [0..10] queries by
+ * number of generic levels, [11] queries that used the jump table, [12] wave iterations, [13..15] sums of
+ * the per-wave maxima of generic levels / fast levels / leaf size, [16..26] wave iterations by max generic */
+int pft_debug_get_descent_stats(pft_tracker* t, uint64_t* dbg32);
 int pft_debug_normalize(pft_tracker* t, float* w_inout, size_t n, double* fit_ratio);
 int pft_debug_alias(pft_tracker* t, const float* w, size_t n, int32_t* a, double* q);
 int pft_debug_weighted_mean(pft_tracker* t, const pft_particle* p, size_t n, pft_particle* out);

@@ -66,6 +66,8 @@ SYMBOLS = [
     ("pft_debug_get_octree", C.c_int, [_vp, _P(_i32), _vp, _vp, _P(_u32), _P(_u32)]),
     ("pft_debug_get_point_keys", C.c_int, [_vp, _vp, _sz]),
     ("pft_debug_get_scan_stats", C.c_int, [_vp, _P(_u64), _P(_u64)]),
+    ("pft_debug_get_ticks", C.c_int, [_vp, _vp]),
+    ("pft_debug_get_descent_stats", C.c_int, [_vp, _vp]),
     ("pft_debug_normalize", C.c_int, [_vp, _vp, _sz, _P(_f64)]),
     ("pft_debug_alias", C.c_int, [_vp, _vp, _sz, _vp, _vp]),
     ("pft_debug_weighted_mean", C.c_int, [_vp, _vp, _sz, _vp]),

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -50,14 +52,15 @@ struct pft_tracker {
   uint32_t* d_words = nullptr;
   uint32_t max_words = 0;
   float* d_centers = nullptr;
+  uint16_t* d_jump = nullptr;
+  uint32_t* d_ref_perm = nullptr;
   float4* d_leaf_pts = nullptr;
-  uint32_t *d_leaf_order = nullptr, *d_pt_node = nullptr, *d_pt_key = nullptr, *d_pt_tmp = nullptr,
-           *d_leaf_cursor = nullptr;
+  uint32_t *d_leaf_order = nullptr, *d_pt_node = nullptr, *d_pt_key = nullptr, *d_pt_tmp = nullptr;
+  unsigned long long* d_pt_key64 = nullptr;
   double* d_partial = nullptr;
-  int32_t* d_alias_a = nullptr;
-  double* d_alias_q = nullptr;
   int32_t* d_alias_list = nullptr;
   double* d_alias_pref = nullptr;
+  uint32_t* d_alias_pos = nullptr;
   PftHeader* d_hdr = nullptr;
   int32_t* d_nn_idx = nullptr;
   float* d_nn_d2 = nullptr;
@@ -245,17 +248,18 @@ static void sync_dev(pft_tracker* t) {
   d.words = t->d_words;
   d.max_words = t->max_words;
   d.centers = t->d_centers;
+  d.jump = t->d_jump;
+  d.ref_perm = t->d_ref_perm;
   d.leaf_pts = t->d_leaf_pts;
   d.leaf_order = t->d_leaf_order;
   d.pt_node = t->d_pt_node;
   d.pt_key = t->d_pt_key;
   d.pt_tmp = t->d_pt_tmp;
-  d.leaf_cursor = t->d_leaf_cursor;
+  d.pt_key64 = t->d_pt_key64;
   d.partial = t->d_partial;
-  d.alias_a = t->d_alias_a;
-  d.alias_q = t->d_alias_q;
   d.alias_list = t->d_alias_list;
   d.alias_pref = t->d_alias_pref;
+  d.alias_pos = t->d_alias_pos;
   d.hdr = t->d_hdr;
   d.nn_idx = t->d_nn_idx;
   d.nn_d2 = t->d_nn_d2;
@@ -270,7 +274,7 @@ static int ensure_input_capacity(pft_tracker* t, uint32_t n) {
   hipStreamSynchronize(t->stream);
   dfree(t->d_in_raw); dfree(t->d_in_pts); dfree(t->d_crop_counts); dfree(t->d_crop_pts); dfree(t->d_crop_idx);
   dfree(t->d_words); dfree(t->d_leaf_pts); dfree(t->d_leaf_order); dfree(t->d_pt_node); dfree(t->d_pt_key);
-  dfree(t->d_pt_tmp); dfree(t->d_leaf_cursor);
+  dfree(t->d_pt_tmp); dfree(t->d_pt_key64);
   uint32_t cap = n;
   t->max_words = cap * 8u + 64u;
   HIPCHK(t, dalloc(&t->d_in_raw, cap));
@@ -284,7 +288,7 @@ static int ensure_input_capacity(pft_tracker* t, uint32_t n) {
   HIPCHK(t, dalloc(&t->d_pt_node, cap));
   HIPCHK(t, dalloc(&t->d_pt_key, (size_t)cap * 3));
   HIPCHK(t, dalloc(&t->d_pt_tmp, cap));
-  HIPCHK(t, dalloc(&t->d_leaf_cursor, cap));
+  HIPCHK(t, dalloc(&t->d_pt_key64, cap));
   t->in_cap = cap;
   return PFT_OK;
 }
@@ -296,6 +300,7 @@ extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
       cfg->world_size <= 0 || cfg->rank < 0 || cfg->rank >= cfg->world_size || cfg->use_normal != 0 ||
       cfg->particle_num % cfg->world_size != 0 || !(cfg->octree_resolution > 0))
     return PFT_ERR_INVALID_ARG;
+  if (cfg->particle_num > PFT_MAX_PARTICLES) return PFT_ERR_CAPACITY;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device_id >= ndev) return PFT_ERR_NO_DEVICE;
   if (hipSetDevice(cfg->device_id) != hipSuccess) return PFT_ERR_NO_DEVICE;
@@ -349,10 +354,10 @@ extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
   A(dalloc(&t->d_bbox_part, (size_t)t->num_cus * 6));
   A(dalloc(&t->d_bbox6, 8));
   A(dalloc(&t->d_centers, (size_t)3 * (2u << PFT_TABLE_MAX_DEPTH)));
-  A(dalloc(&t->d_alias_a, Pt));
-  A(dalloc(&t->d_alias_q, Pt));
+  A(dalloc(&t->d_jump, (size_t)1 << (3 * PFT_JUMP_MAX_LEVEL)));
   A(dalloc(&t->d_alias_list, 2 * Pt));
   A(dalloc(&t->d_alias_pref, 2 * Pt));
+  A(dalloc(&t->d_alias_pos, Pt));
   A(dalloc(&t->d_hdr, 1));
   A(dalloc(&t->d_dbg_hdr, 1));
   if (e == hipSuccess) e = hipMemsetAsync(t->d_hdr, 0, sizeof(PftHeader), t->stream);
@@ -388,9 +393,9 @@ extern "C" void pft_destroy(pft_tracker* t) {
   dfree(t->d_ref_raw); dfree(t->d_ref_xyz); dfree(t->d_ref_hsv);
   dfree(t->d_in_raw); dfree(t->d_in_pts);
   dfree(t->d_part[0]); dfree(t->d_part[1]); dfree(t->d_mats); dfree(t->d_bbox_part); dfree(t->d_bbox6);
-  dfree(t->d_crop_counts); dfree(t->d_crop_pts); dfree(t->d_crop_idx); dfree(t->d_words); dfree(t->d_centers);
+  dfree(t->d_crop_counts); dfree(t->d_crop_pts); dfree(t->d_crop_idx); dfree(t->d_words); dfree(t->d_centers); dfree(t->d_jump); dfree(t->d_ref_perm);
   dfree(t->d_leaf_pts); dfree(t->d_leaf_order); dfree(t->d_pt_node); dfree(t->d_pt_key); dfree(t->d_pt_tmp);
-  dfree(t->d_leaf_cursor); dfree(t->d_partial); dfree(t->d_alias_a); dfree(t->d_alias_q); dfree(t->d_alias_list);
+  dfree(t->d_pt_key64); dfree(t->d_partial); dfree(t->d_alias_list); dfree(t->d_alias_pos);
   dfree(t->d_alias_pref); dfree(t->d_hdr); dfree(t->d_nn_idx); dfree(t->d_nn_d2); dfree(t->d_dbg_part);
   dfree(t->d_dbg_hdr); dfree(t->d_dbg_f);
   if (t->own_stream && t->stream) hipStreamDestroy(t->stream);
@@ -408,10 +413,12 @@ extern "C" int pft_synchronize(pft_tracker* t) {
 extern "C" int pft_set_reference(pft_tracker* t, const pft_point_xyzrgba* pts, size_t n) {
   if (!t || (!pts && n)) return PFT_ERR_INVALID_ARG;
   if (n > 0x7fffffffu) return PFT_ERR_CAPACITY;
+  hipSetDevice(t->cfg.device_id);
   if (n > t->ref_cap) {
     hipStreamSynchronize(t->stream);
-    dfree(t->d_ref_raw); dfree(t->d_ref_xyz); dfree(t->d_ref_hsv); dfree(t->d_partial);
+    dfree(t->d_ref_raw); dfree(t->d_ref_xyz); dfree(t->d_ref_hsv); dfree(t->d_partial); dfree(t->d_ref_perm);
     HIPCHK(t, dalloc(&t->d_ref_raw, n));
+    HIPCHK(t, dalloc(&t->d_ref_perm, n));
     HIPCHK(t, dalloc(&t->d_ref_xyz, n));
     HIPCHK(t, dalloc(&t->d_ref_hsv, n));
     t->ref_cap = (uint32_t)n;
@@ -422,6 +429,46 @@ extern "C" int pft_set_reference(pft_tracker* t, const pft_point_xyzrgba* pts, s
   dfree(t->d_partial);
   HIPCHK(t, dalloc(&t->d_partial, (size_t)t->prm.P_local * t->prm.nchunk));
   if (n) {
+    // The reference cloud is stored in Morton (Z-curve) order: the 64 lanes of a wave then query
+    // neighbouring space, so their octree paths and leaf records share LDS words and cache lines.  Every
+    // per-particle result is a sum over all reference points, so the order is free; ref_perm maps back.
+    std::vector<uint32_t> perm(n);
+    std::vector<pft_point_xyzrgba> sorted(n);
+    {
+      float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      for (size_t i = 0; i < n; i++) {
+        const float c[3] = {pts[i].x, pts[i].y, pts[i].z};
+        for (int a = 0; a < 3; a++)
+          if (std::isfinite(c[a])) {
+            lo[a] = std::min(lo[a], c[a]);
+            hi[a] = std::max(hi[a], c[a]);
+          }
+      }
+      float ext = 0.0f;
+      for (int a = 0; a < 3; a++)
+        if (hi[a] >= lo[a]) ext = std::max(ext, hi[a] - lo[a]);
+      const float scale = ext > 0.0f ? 1023.0f / ext : 0.0f;
+      std::vector<uint64_t> code(n);
+      for (size_t i = 0; i < n; i++) {
+        const float c[3] = {pts[i].x, pts[i].y, pts[i].z};
+        uint64_t m = 0;
+        uint32_t q[3];
+        for (int a = 0; a < 3; a++) {
+          float v = std::isfinite(c[a]) ? (c[a] - lo[a]) * scale : 0.0f;
+          q[a] = (uint32_t)std::min(1023.0f, std::max(0.0f, v));
+        }
+        for (int b = 9; b >= 0; b--)
+          m = (m << 3) | (uint64_t)((((q[0] >> b) & 1u) << 2) | (((q[1] >> b) & 1u) << 1) | ((q[2] >> b) & 1u));
+        code[i] = (m << 32) | (uint64_t)i;  // index in the low bits: stable
+      }
+      std::sort(code.begin(), code.end());
+      for (size_t i = 0; i < n; i++) {
+        perm[i] = (uint32_t)(code[i] & 0xffffffffu);
+        sorted[i] = pts[perm[i]];
+      }
+    }
+    pts = sorted.data();
+    HIPCHK(t, hipMemcpyAsync(t->d_ref_perm, perm.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
     HIPCHK(t, hipMemcpyAsync(t->d_ref_raw, pts, n * sizeof(pft_point_xyzrgba), hipMemcpyHostToDevice, t->stream));
     pftk_pack_reference(t->stream, t->d_ref_raw, (uint32_t)n, t->prm.hsv_argorder, t->d_ref_xyz, t->d_ref_hsv);
     HIPCHK(t, hipStreamSynchronize(t->stream));
@@ -440,6 +487,7 @@ extern "C" int pft_set_trans(pft_tracker* t, const float m[16]) {
 static int set_input_common(pft_tracker* t, const void* src, size_t n, bool device) {
   if (!t || (!src && n)) return PFT_ERR_INVALID_ARG;
   if (n > 0x7fffffffu) return PFT_ERR_CAPACITY;
+  hipSetDevice(t->cfg.device_id);
   int r = ensure_input_capacity(t, (uint32_t)n);
   if (r != PFT_OK) return r;
   t->N = (uint32_t)n;
@@ -493,15 +541,16 @@ static void stage_resample(pft_tracker* t) {
 }
 
 // A2+A3 (fused; transformed clouds are never materialised)
-static void stage_aabb(pft_tracker* t, const PftDev& d, uint32_t np) {
+static void stage_aabb(pft_tracker* t, const PftDev& d, uint32_t np, bool finalize) {
   ProfScope ps(t, PFT_K_AABB);
-  pftk_aabb(t->stream, t->prm, d, np);
+  pftk_aabb(t->stream, t->prm, d, np, finalize);
 }
 // A4, A5, A6+A7
-static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32_t np, bool debug_nn) {
+static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32_t np, bool debug_nn,
+                                         bool bbox_from_partials) {
   {
     ProfScope ps(t, PFT_K_CROP);
-    pftk_crop(t->stream, t->prm, d);
+    pftk_crop(t->stream, t->prm, d, bbox_from_partials);
   }
   {
     ProfScope ps(t, PFT_K_OCTREE);
@@ -520,6 +569,7 @@ __global__ void k_copy_particles(const pft_particle* __restrict__ src, pft_parti
 
 static int check_ready(pft_tracker* t) {
   if (!t) return PFT_ERR_INVALID_ARG;
+  hipSetDevice(t->cfg.device_id);
   if (!t->has_input || t->N == 0) return PFT_ERR_NO_INPUT;  // PCL: PCL_ERROR + early return
   if (!t->has_ref) return PFT_ERR_NO_REFERENCE;
   return PFT_OK;
@@ -536,13 +586,13 @@ extern "C" int pft_compute(pft_tracker* t) {
   for (int it = 0; it < t->cfg.iteration_num; it++) {
     if (t->changed) stage_resample(t);
     sync_dev(t);
-    stage_aabb(t, t->dev, t->prm.P_local);
-    stage_crop_octree_likelihood(t, t->dev, t->prm.P_local, false);
+    stage_aabb(t, t->dev, t->prm.P_local, false);
+    stage_crop_octree_likelihood(t, t->dev, t->prm.P_local, false, true);
     {
       ProfScope ps(t, PFT_K_POPULATION);
-      pftk_finalize_raw(t->stream, t->prm, t->dev, t->prm.P_local, nullptr);
-      // weight() ends with normalizeWeight(); use_change_detector_ == false => changed_ = true => update()
-      pftk_population(t->stream, t->prm, t->dev, t->prm.P_total, 1, 1, 1);
+      // raw weights from the partial sums, then weight()'s normalizeWeight(); use_change_detector_ == false
+      // => changed_ = true => update(); the alias prefix form feeds the next resample
+      pftk_population(t->stream, t->prm, t->dev, t->prm.P_total, 1, 1, 1, 1);
     }
     t->changed = true;
   }
@@ -582,7 +632,7 @@ extern "C" int pft_dist_phase_a(pft_tracker* t, int iteration) {
   if (!t->initialized) return PFT_ERR_STATE;
   if (t->changed) stage_resample(t);
   sync_dev(t);
-  stage_aabb(t, t->dev, t->prm.P_local);
+  stage_aabb(t, t->dev, t->prm.P_local, true);
   return PFT_OK;
 }
 
@@ -590,7 +640,7 @@ extern "C" int pft_dist_phase_b(pft_tracker* t) {
   int r = check_ready(t);
   if (r != PFT_OK) return r;
   sync_dev(t);
-  stage_crop_octree_likelihood(t, t->dev, t->prm.P_local, false);
+  stage_crop_octree_likelihood(t, t->dev, t->prm.P_local, false, false);
   {
     ProfScope ps(t, PFT_K_POPULATION);
     pftk_finalize_raw(t->stream, t->prm, t->dev, t->prm.P_local, nullptr);
@@ -606,7 +656,7 @@ extern "C" int pft_dist_phase_c(pft_tracker* t) {
   sync_dev(t);
   {
     ProfScope ps(t, PFT_K_POPULATION);
-    pftk_population(t->stream, t->prm, t->dev, t->prm.P_total, 1, 1, 1);
+    pftk_population(t->stream, t->prm, t->dev, t->prm.P_total, 0, 1, 1, 1);
   }
   t->changed = true;
   return PFT_OK;
@@ -699,10 +749,10 @@ extern "C" int pft_eval_weights(pft_tracker* t, const pft_particle* particles, s
   d.part_all = t->d_dbg_part;
   d.bbox6 = t->d_bbox6;
   HIPCHK(t, hipMemcpyAsync(t->d_dbg_part, particles, P * sizeof(pft_particle), hipMemcpyHostToDevice, t->stream));
-  HIPCHK(t, hipMemsetAsync(&t->d_hdr->stat_queries, 0, 2 * sizeof(unsigned long long), t->stream));
+  HIPCHK(t, hipMemsetAsync(&t->d_hdr->stat_queries, 0, (2 + 32) * sizeof(unsigned long long), t->stream));
   pftk_pose_to_matrix(t->stream, t->d_dbg_part, (uint32_t)P, t->d_mats);
-  stage_aabb(t, d, (uint32_t)P);
-  stage_crop_octree_likelihood(t, d, (uint32_t)P, want_nn);
+  stage_aabb(t, d, (uint32_t)P, false);
+  stage_crop_octree_likelihood(t, d, (uint32_t)P, want_nn, true);
   pftk_finalize_raw(t->stream, t->prm, d, (uint32_t)P, t->d_dbg_f);
   if (raw_w) HIPCHK(t, hipMemcpyAsync(raw_w, t->d_dbg_f, P * sizeof(float), hipMemcpyDeviceToHost, t->stream));
   if (nn_idx) HIPCHK(t, hipMemcpyAsync(nn_idx, t->d_nn_idx, pairs * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
@@ -770,6 +820,24 @@ extern "C" int pft_debug_get_point_keys(pft_tracker* t, uint32_t* keys3, size_t 
   return PFT_OK;
 }
 
+extern "C" int pft_debug_get_ticks(pft_tracker* t, uint64_t* ticks32) {
+  if (!t || !ticks32) return PFT_ERR_INVALID_ARG;
+  PftHeader h;
+  int r = read_hdr(t, &h);
+  if (r != PFT_OK) return r;
+  for (int i = 0; i < 32; i++) ticks32[i] = h.ticks[i];
+  return PFT_OK;
+}
+
+extern "C" int pft_debug_get_descent_stats(pft_tracker* t, uint64_t* dbg32) {
+  if (!t || !dbg32) return PFT_ERR_INVALID_ARG;
+  PftHeader h;
+  int r = read_hdr(t, &h);
+  if (r != PFT_OK) return r;
+  for (int i = 0; i < 32; i++) dbg32[i] = h.dbg[i];
+  return PFT_OK;
+}
+
 extern "C" int pft_debug_get_scan_stats(pft_tracker* t, uint64_t* queries, uint64_t* scanned) {
   if (!t) return PFT_ERR_INVALID_ARG;
   PftHeader h;
@@ -787,8 +855,9 @@ struct DbgPop {
   double* q = nullptr;
   int32_t* list = nullptr;
   double* pref = nullptr;
+  uint32_t* pos = nullptr;
   ~DbgPop() {
-    dfree(part); dfree(a); dfree(q); dfree(list); dfree(pref);
+    dfree(part); dfree(a); dfree(q); dfree(list); dfree(pref); dfree(pos);
   }
 };
 
@@ -800,17 +869,18 @@ static int dbg_population(pft_tracker* t, std::vector<pft_particle>& host, int n
   HIPCHK(t, dalloc(&b.q, n));
   HIPCHK(t, dalloc(&b.list, 2 * n));
   HIPCHK(t, dalloc(&b.pref, 2 * n));
+  HIPCHK(t, dalloc(&b.pos, n));
   HIPCHK(t, hipMemcpyAsync(b.part, host.data(), n * sizeof(pft_particle), hipMemcpyHostToDevice, t->stream));
   HIPCHK(t, hipMemsetAsync(t->d_dbg_hdr, 0, sizeof(PftHeader), t->stream));
   sync_dev(t);
   PftDev d = t->dev;
   d.part_all = b.part;
-  d.alias_a = b.a;
-  d.alias_q = b.q;
   d.alias_list = b.list;
   d.alias_pref = b.pref;
+  d.alias_pos = b.pos;
   d.hdr = t->d_dbg_hdr;
-  pftk_population(t->stream, t->prm, d, (uint32_t)n, norm, mean, alias);
+  pftk_population(t->stream, t->prm, d, (uint32_t)n, 0, norm, mean, alias);
+  if (alias) pftk_alias_materialize(t->stream, d, (uint32_t)n, b.a, b.q);
   HIPCHK(t, hipMemcpyAsync(host.data(), b.part, n * sizeof(pft_particle), hipMemcpyDeviceToHost, t->stream));
   if (hout) HIPCHK(t, hipMemcpyAsync(hout, t->d_dbg_hdr, sizeof(PftHeader), hipMemcpyDeviceToHost, t->stream));
   HIPCHK(t, hipStreamSynchronize(t->stream));
@@ -894,13 +964,7 @@ extern "C" int pft_debug_resample(pft_tracker* t, const pft_particle* old, size_
     p.id_offset = id_offset;
     p.P_local = (uint32_t)n_local;
     p.P_total = (uint32_t)n_total;
-    PftDev d = t->dev;
-    d.part_all = d_old;
-    d.alias_a = d_a;
-    d.alias_q = d_q;
-    d.hdr = t->d_dbg_hdr;
-    d.mats = nullptr;
-    pftk_resample(t->stream, p, d, epoch, d_out);
+    pftk_resample_table(t->stream, p, d_old, d_a, d_q, t->d_dbg_hdr, epoch, d_out);
     e = hipMemcpyAsync(out, d_out, n_local * sizeof(pft_particle), hipMemcpyDeviceToHost, t->stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(t->stream);

@@ -12,7 +12,7 @@
 //   centers             float[3][2^(D+1)] per-level per-axis voxel-centre tables                 (A6)
 //   leaf_pts            float4[N]   cropped points in leaf order (insertion order inside a leaf)
 //   partial             double[P_local*nchunk] per (particle, reference chunk) likelihood sums   (A7)
-//   alias_a / alias_q   int[P] / double[P]                                                       (A9)
+//   alias_list/pref/pos prefix-sum form of the Walker alias table over all P particles          (A9)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,10 +22,12 @@
 #define PFT_MAX_DEPTH 30
 #define PFT_TABLE_MAX_DEPTH 10
 #define PFT_MAX_GROW 40
+#define PFT_JUMP_MAX_LEVEL 5     // 2^15 cells x u16 = 64 KiB of LDS in the likelihood kernel
 #define PFT_REF_CHUNK 512        // reference points per likelihood work item
-#define PFT_BUILD_THREADS 1024
+#define PFT_BUILD_THREADS 512
 #define PFT_LIK_THREADS 1024
 #define PFT_POP_THREADS 1024
+#define PFT_MAX_PARTICLES (64 * PFT_POP_THREADS)  // population kernel: <= 64 particles per thread
 
 struct PftParams {  // immutable per handle, passed by value to kernels
   double alpha;
@@ -43,7 +45,7 @@ struct PftParams {  // immutable per handle, passed by value to kernels
 struct PftHeader {  // lives in HBM; written by kernels, read by later kernels (and by the host for debug)
   float bbox[6];    // x_min,x_max,y_min,y_max,z_min,z_max
   uint32_t n_crop;
-  uint32_t error;   // bit0: octree capacity exceeded, bit1: depth exceeded
+  uint32_t error;   // bit0: octree capacity exceeded, bit1: depth / growth steps exceeded
   double omin[3], omax[3];
   int32_t depth;
   int32_t use_table;
@@ -52,14 +54,19 @@ struct PftHeader {  // lives in HBM; written by kernels, read by later kernels (
   uint32_t leaf_start;  // index of first leaf word
   uint32_t lvl_start[PFT_MAX_DEPTH + 3];
   int32_t n_grow;
-  uint32_t grow_idx[PFT_MAX_GROW];
-  uint32_t grow_shift[PFT_MAX_GROW];  // bit a set: axis a min lowered
-  uint32_t grow_old_depth[PFT_MAX_GROW];
-  double grow_min[PFT_MAX_GROW + 1][3];  // [e] = min valid for epoch e
+  int32_t build_path;   // 1 = register/LDS-resident builder, 0 = generic builder (diagnostic)
+  // fast descent (pft_likelihood.hip): direct-index table of the level-J nodes and the safety margin
+  int32_t jump_level;   // J (0 = no table): jump[kx | ky<<J | kz<<2J] = 1 + index of the node inside level J
+  float margin_cells;   // a query closer than this (in leaf cells) to a cell face takes the exact generic step
+  float ominf[3];       // (float) omin
+  float inv_res;        // (float)(1/res)
   double fit_ratio;
   pft_particle rep;
   pft_particle motion;
+  uint32_t alias_m, alias_nh;   // sizes of the small / large lists
   unsigned long long stat_queries, stat_scanned;
+  unsigned long long dbg[32];    // debug-variant likelihood statistics (tools/descent_stats.py)
+  unsigned long long ticks[32];  // wall_clock64() (100 MHz) at phase boundaries: [0..15] octree, [16..31] population
 };
 
 struct PftDev {  // device pointers (host-side struct, passed by value)
@@ -79,37 +86,45 @@ struct PftDev {  // device pointers (host-side struct, passed by value)
   uint32_t* words;
   uint32_t max_words;
   float* centers;
+  uint16_t* jump;           // [2^(3*PFT_JUMP_MAX_LEVEL)]
+  const uint32_t* ref_perm; // sorted reference position -> index in the caller's reference cloud
   float4* leaf_pts;
   uint32_t* leaf_order;
   uint32_t* pt_node;
-  uint32_t* pt_key;     // 3 per point
+  uint32_t* pt_key;     // 3 per point (final-frame keys; read back by the debug hook)
+  unsigned long long* pt_key64;  // packed keys of the generic (HBM-resident) builder path
   uint32_t* pt_tmp;
-  uint32_t* leaf_cursor;
   double* partial;
-  int32_t* alias_a;
-  double* alias_q;
-  int32_t* alias_list;   // 2*P scratch: L list, H list
-  double* alias_pref;    // 2*P scratch: D, E prefix sums
+  int32_t* alias_list;   // [0,P): small list, [P,2P): large list
+  double* alias_pref;    // [0,P): running deficit, [P,2P): running excess
+  uint32_t* alias_pos;   // [P]
   PftHeader* hdr;
   int32_t* nn_idx;      // debug only
   float* nn_d2;
 };
 
-// launchers (pft_kernels.hip)
+// launchers
 void pftk_pack_reference(hipStream_t s, const pft_point_xyzrgba* d_pts, uint32_t n, int argorder, float4* xyz,
                          float4* hsv);
 void pftk_pack_input(hipStream_t s, const pft_point_xyzrgba* d_pts, uint32_t n, float4* out);
 void pftk_init_particles(hipStream_t s, const PftParams& p, pft_particle rep, pft_particle* out, float* mats,
                          PftHeader* hdr);
 void pftk_resample(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t epoch, pft_particle* out);
+// debug: resample from an explicit (a, q) table instead of the prefix-sum form
+void pftk_resample_table(hipStream_t s, const PftParams& p, const pft_particle* old, const int32_t* a,
+                         const double* q, const PftHeader* hdr, uint32_t epoch, pft_particle* out);
 void pftk_pose_to_matrix(hipStream_t s, const pft_particle* p, uint32_t n, float* mats);
-void pftk_aabb(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles);
-void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d);
+void pftk_aabb(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, bool finalize);
+void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d, bool bbox_from_partials);
 void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d);
 void pftk_likelihood(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, bool debug_nn,
                      int num_cus);
 void pftk_finalize_raw(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles,
                        float* raw_out /*nullable*/);
-void pftk_population(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n /*particles in part_all*/,
+// normalise + update + alias prefix form over part_all[0..n); when partial != null the raw weights are
+// first formed from the likelihood partial sums (single-GPU path: fuses k_finalize_raw)
+void pftk_population(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n, int from_partials,
                      int do_normalize, int do_mean, int do_alias);
+// debug: materialise the (a, q) table from the prefix-sum form
+void pftk_alias_materialize(hipStream_t s, const PftDev& d, uint32_t n, int32_t* a, double* q);
 int pftk_max_lds_bytes();

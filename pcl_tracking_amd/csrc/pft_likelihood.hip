@@ -1,0 +1,352 @@
+// pft_likelihood.hip -- A6 + A7, the dominant kernel: per (particle, reference point)
+//   transform (A2, recomputed in registers) -> greedy closest-child-centre descent
+//   (OctreePointCloudSearch::approxNearestSearchRecursive, octree/impl/octree_search.hpp) -> leaf scan
+//   -> gate d2 < max_distance^2 -> DistanceCoherence x HSVColorCoherence
+//   (tracking/impl/approx_nearest_pair_point_cloud_coherence.hpp), summed per particle in double.
+//
+// One persistent 1024-thread workgroup per CU stages the linearised octree (node words, per-level centre
+// tables, the level-J jump table, hue/saturation LUTs) into LDS once; each wave then walks work items
+// (particle, chunk of 512 Morton-ordered reference points): the particle's 3x4 matrix is wave-uniform,
+// reference points are read coalesced, the descent runs in registers against LDS, leaf records (16 B) are
+// gathered from L2, and the per-lane double partial sums are combined with wave shuffles.
+//
+// Descent.  PCL picks, at every level, the EXISTING child whose voxel centre is closest to the query
+// (float squared distances, ties to the lowest child index).  While the child that CONTAINS the query
+// exists, that child is the strict minimum, so the step needs only the query's integer key bits:
+//   * jump: the level-J ancestor (J <= 5) is looked up directly in a dense table;
+//   * fast levels: follow the key bit while the containing child exists;
+//   * generic levels: the exact float evaluation of all existing children, as PCL does it.
+// The shortcut is taken only when the query is farther than `margin` from every face of the cells
+// involved (float rounding of centres and sums can reorder children only inside that band: DESIGN.md
+// "fast descent"); otherwise the level is evaluated generically.  Results are bit-identical to the
+// all-generic descent (tests/test_gpu_parity.py compares index and distance of every pair).
+// Algorithmic bytes per pair-eval: 16 (reference point) + 16 per candidate scanned in the reached leaf.
+#include "pft_device_utils.h"
+
+struct LikCtx {
+  const uint32_t* words;   // LDS or HBM
+  const float* tab;        // per-axis centre tables, stride per_axis
+  uint32_t per_axis;
+  const float* lut_h;      // [256] h/180
+  const float* lut_s;      // [256] s/255
+  const uint16_t* jump;    // LDS, or null
+  int J;
+  uint32_t lvlJ_start;
+  float margin, ominx, ominy, ominz, inv_res, ncell;
+};
+
+__device__ __forceinline__ double rcp_nr(double x) {
+  // 1/x for x in [1, 2): hardware estimate + two Newton steps (full double precision up to ~1 ulp)
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  return r;
+}
+
+// true if the query is within the margin of a face of its cell of 2^sh leaf cells per side
+__device__ __forceinline__ bool face_violation(uint32_t kx, uint32_t ky, uint32_t kz, uint32_t lowf, uint32_t highf,
+                                               int sh) {
+  const uint32_t mx = (1u << sh) - 1u;
+  const uint32_t rx = kx & mx, ry = ky & mx, rz = kz & mx;
+  bool v = ((lowf & 1u) && rx == 0) || ((highf & 1u) && rx == mx);
+  v |= ((lowf & 2u) && ry == 0) || ((highf & 2u) && ry == mx);
+  v |= ((lowf & 4u) && rz == 0) || ((highf & 4u) && rz == mx);
+  return v;
+}
+
+template <bool USE_TAB, bool FAST, bool DEBUG_NN>
+__device__ __forceinline__ void likelihood_items(const PftParams& prm, const PftDev& d, const LikCtx& cx,
+                                                 uint32_t n_particles, int D, uint32_t n_crop,
+                                                 const double omin[3]) {
+  const int lane = lane_id(), w = wave_id(), nw = blockDim.x >> 6;
+  const uint32_t gw = blockIdx.x * nw + w, tw = gridDim.x * nw;
+  const uint32_t M = prm.M, nchunk = prm.nchunk;
+  const uint32_t n_items = n_particles * nchunk;
+  const double res = prm.res;
+  const double maxd2 = prm.maxd2;
+  const double wd = prm.dist_w, whsv = prm.hsv_w;
+  const float hw = prm.h_w, sw = prm.s_w, vw = prm.v_w;
+  const uint32_t* W = cx.words;
+
+  for (uint32_t item = gw; item < n_items; item += tw) {
+    const uint32_t pi = item / nchunk, ch = item % nchunk;
+    float T[12];
+    load_matrix(d.mats, pi, T);
+    double val = 0.0;
+    unsigned long long st_q = 0, st_s = 0;
+    const uint32_t jend = min(M, (ch + 1) * (uint32_t)PFT_REF_CHUNK);
+    for (uint32_t j = ch * PFT_REF_CHUNK + lane; j < jend; j += WAVE) {
+      const float4 r = d.ref_xyz[j];
+      float qx, qy, qz;
+      xform(T, r.x, r.y, r.z, qx, qy, qz);
+      if (n_crop == 0) {  // empty target: PCL asserts; defined as "no correspondence"
+        if (DEBUG_NN) {
+          const size_t o = (size_t)pi * M + d.ref_perm[j];
+          d.nn_idx[o] = -1;
+          d.nn_d2[o] = INFINITY;
+        }
+        continue;
+      }
+      uint32_t node = 0, pkx = 0, pky = 0, pkz = 0;
+      int lvl = 0;
+      int dbg_fast = 0, dbg_gen = 0, dbg_jump = 0;
+      if (FAST) {
+        // integer key of the query in leaf cells (float: error < 1e-4 cells, far inside the margin)
+        const float tx = (qx - cx.ominx) * cx.inv_res, ty = (qy - cx.ominy) * cx.inv_res,
+                    tz = (qz - cx.ominz) * cx.inv_res;
+        const float flx = floorf(tx), fly = floorf(ty), flz = floorf(tz);
+        bool inside = (tx >= 0.0f) && (tx < cx.ncell) && (ty >= 0.0f) && (ty < cx.ncell) && (tz >= 0.0f) &&
+                      (tz < cx.ncell);
+        const float fx = tx - flx, fy = ty - fly, fz = tz - flz;
+        const float mg = cx.margin, mh = 1.0f - cx.margin;
+        const uint32_t lowf = (fx < mg ? 1u : 0u) | (fy < mg ? 2u : 0u) | (fz < mg ? 4u : 0u);
+        const uint32_t highf = (fx > mh ? 1u : 0u) | (fy > mh ? 2u : 0u) | (fz > mh ? 4u : 0u);
+        const bool risky = (lowf | highf) != 0u;
+        const uint32_t kx = inside ? (uint32_t)flx : 0u, ky = inside ? (uint32_t)fly : 0u,
+                       kz = inside ? (uint32_t)flz : 0u;
+        if (inside && cx.J > 0) {
+          const int sh = D - cx.J;
+          if (!(risky && face_violation(kx, ky, kz, lowf, highf, sh))) {
+            const uint32_t e = cx.jump[(kx >> sh) | ((ky >> sh) << cx.J) | ((kz >> sh) << (2 * cx.J))];
+            if (e) {  // all ancestors of an existing node exist and contain the query
+              node = cx.lvlJ_start + e - 1u;
+              lvl = cx.J;
+              dbg_jump = 1;
+            }
+          }
+        }
+        // fast levels: follow the key while the child containing the query exists
+        while (inside && lvl < D) {
+          const int sh = D - lvl - 1;
+          const uint32_t c = (((kx >> sh) & 1u) << 2) | (((ky >> sh) & 1u) << 1) | ((kz >> sh) & 1u);
+          const uint32_t wv = W[node];
+          if (!((wv >> c) & 1u)) break;
+          if (risky && face_violation(kx, ky, kz, lowf, highf, sh)) break;
+          node = (wv >> 8) + __popc(wv & 0xffu & ((1u << c) - 1u));
+          lvl++;
+          dbg_fast++;
+        }
+        const int up = D - lvl;
+        pkx = kx >> up; pky = ky >> up; pkz = kz >> up;  // path key of `node` (zero at the root)
+      }
+      // ---- generic levels: exact float evaluation of the existing children ----
+      for (; lvl < D; lvl++) {
+        dbg_gen++;
+        const uint32_t wv = W[node];
+        const uint32_t mask = wv & 0xffu, base = wv >> 8;
+        float cx0, cx1, cy0, cy1, cz0, cz1;
+        if (USE_TAB) {
+          const uint32_t off = (2u << lvl) - 2u;  // children live at level lvl + 1
+          const float2 tx2 = *reinterpret_cast<const float2*>(cx.tab + off + 2u * pkx);
+          const float2 ty2 = *reinterpret_cast<const float2*>(cx.tab + cx.per_axis + off + 2u * pky);
+          const float2 tz2 = *reinterpret_cast<const float2*>(cx.tab + 2u * cx.per_axis + off + 2u * pkz);
+          cx0 = tx2.x; cx1 = tx2.y; cy0 = ty2.x; cy1 = ty2.y; cz0 = tz2.x; cz1 = tz2.y;
+        } else {
+          const double vs = res * (double)(1u << (D - lvl - 1));
+          cx0 = (float)(((double)(2u * pkx) + 0.5) * vs + omin[0]);
+          cx1 = (float)(((double)(2u * pkx + 1u) + 0.5) * vs + omin[0]);
+          cy0 = (float)(((double)(2u * pky) + 0.5) * vs + omin[1]);
+          cy1 = (float)(((double)(2u * pky + 1u) + 0.5) * vs + omin[1]);
+          cz0 = (float)(((double)(2u * pkz) + 0.5) * vs + omin[2]);
+          cz1 = (float)(((double)(2u * pkz + 1u) + 0.5) * vs + omin[2]);
+        }
+        // pointSquaredDist: Vector3f difference, squaredNorm = x2 + (y2 + z2)
+        float dx0 = cx0 - qx, dx1 = cx1 - qx, dy0 = cy0 - qy, dy1 = cy1 - qy, dz0 = cz0 - qz, dz1 = cz1 - qz;
+        float X0 = dx0 * dx0, X1 = dx1 * dx1, Y0 = dy0 * dy0, Y1 = dy1 * dy1, Z0 = dz0 * dz0, Z1 = dz1 * dz1;
+        float yz[4] = {Y0 + Z0, Y0 + Z1, Y1 + Z0, Y1 + Z1};
+        float best = INFINITY;
+        uint32_t bc = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < 8; c++) {
+          float dc = ((c & 4u) ? X1 : X0) + yz[c & 3u];
+          bool ex = (mask >> c) & 1u;
+          if (ex && dc < best) {  // "if (dist >= min) continue": ties keep the lowest child index
+            best = dc;
+            bc = c;
+          }
+        }
+        node = base + __popc(mask & ((1u << bc) - 1u));
+        pkx = 2u * pkx + ((bc >> 2) & 1u);
+        pky = 2u * pky + ((bc >> 1) & 1u);
+        pkz = 2u * pkz + (bc & 1u);
+      }
+      // ---- leaf scan: first strictly-smaller wins (insertion order) ----
+      const uint32_t ls = W[node], le = W[node + 1];
+      float bd = INFINITY;
+      uint32_t bpos = ls;
+      float4 bt = make_float4(0, 0, 0, 0);
+      for (uint32_t pos = ls; pos < le; pos++) {
+        const float4 c = d.leaf_pts[pos];
+        float dx = c.x - qx, dy = c.y - qy, dz = c.z - qz;
+        float dd = dx * dx + (dy * dy + dz * dz);
+        if (dd < bd) {
+          bd = dd;
+          bpos = pos;
+          bt = c;
+        }
+      }
+      if (DEBUG_NN) {
+        const size_t o = (size_t)pi * M + d.ref_perm[j];
+        d.nn_idx[o] = (int32_t)d.leaf_order[bpos];
+        d.nn_d2[o] = bd;
+        st_q += 1;
+        st_s += le - ls;
+        // distribution of the descent work: per query and per wave (max over lanes)
+        atomicAdd(&d.hdr->dbg[dbg_gen < 10 ? dbg_gen : 10], 1ull);
+        atomicAdd(&d.hdr->dbg[11], (unsigned long long)dbg_jump);
+        int mg_ = dbg_gen, mf_ = dbg_fast, ml_ = (int)(le - ls);
+        for (int o = 32; o > 0; o >>= 1) {
+          mg_ = max(mg_, __shfl_xor(mg_, o));
+          mf_ = max(mf_, __shfl_xor(mf_, o));
+          ml_ = max(ml_, __shfl_xor(ml_, o));
+        }
+        if (lane == __ffsll((long long)__ballot(1)) - 1) {
+          atomicAdd(&d.hdr->dbg[12], 1ull);
+          atomicAdd(&d.hdr->dbg[13], (unsigned long long)mg_);
+          atomicAdd(&d.hdr->dbg[14], (unsigned long long)mf_);
+          atomicAdd(&d.hdr->dbg[15], (unsigned long long)ml_);
+          atomicAdd(&d.hdr->dbg[16 + (mg_ < 10 ? mg_ : 10)], 1ull);
+        }
+      }
+      // ---- A7: gate + point coherences ----
+      if ((double)bd < maxd2) {
+        // DistanceCoherence: Vector4f norm (SSE3 packet reduction (dx2+dy2)+(dz2+0)); 1/(1 + d*d*w)
+        float ex = qx - bt.x, ey = qy - bt.y, ez = qz - bt.z;
+        float n2 = (ex * ex + ey * ey) + ez * ez;
+        double dist = (double)sqrtf(n2);
+        double A = 1.0 + dist * dist * wd;
+        // HSVColorCoherence on precomputed (h,s,v): 1/(1 + w * diff2)
+        const float4 rh = d.ref_hsv[j];
+        const uint32_t pk = __float_as_uint(bt.w);
+        const float th = cx.lut_h[pk & 0xffu], ts = cx.lut_s[(pk >> 8) & 0xffu], tv = cx.lut_s[(pk >> 16) & 0xffu];
+        const float hd1 = fabsf(rh.x - th);
+        float hd2;
+        if (rh.x < th)
+          hd2 = fabsf(1.0f + rh.x - th);
+        else
+          hd2 = fabsf(1.0f + th - rh.x);
+        float h_diff;
+        if (hd1 < hd2)
+          h_diff = hw * hd1 * hd1;
+        else
+          h_diff = hw * hd2 * hd2;
+        const float s_diff = sw * (rh.y - ts) * (rh.y - ts);
+        const float v_diff = vw * (rh.z - tv) * (rh.z - tv);
+        const float diff2 = h_diff + s_diff + v_diff;
+        double Bq = 1.0 + whsv * (double)diff2;
+        // (1/A) * (1/B) as one reciprocal of the product: equal to within 2 ulp(double); the per-particle
+        // sum is cast to float afterwards (DESIGN.md "numerics")
+        val += rcp_nr(A * Bq);
+      }
+    }
+    val = wave_sum(val);
+    if (lane == 0) d.partial[(size_t)pi * nchunk + ch] = val;
+    if (DEBUG_NN) {
+      st_q = wave_sum(st_q);
+      st_s = wave_sum(st_s);
+      if (lane == 0 && st_q) {
+        atomicAdd(&d.hdr->stat_queries, st_q);
+        atomicAdd(&d.hdr->stat_scanned, st_s);
+      }
+    }
+  }
+}
+
+template <bool DEBUG_NN>
+__global__ __launch_bounds__(PFT_LIK_THREADS) void k_likelihood(PftParams prm, PftDev d, uint32_t n_particles,
+                                                                uint32_t lds_bytes, int allow_fast) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const PftHeader* hdr = d.hdr;
+  const int D = hdr->depth;
+  const uint32_t n_crop = (hdr->error || D <= 0) ? 0u : hdr->n_crop;
+  const uint32_t n_words = hdr->n_words;
+  const int use_tab = hdr->use_table;
+  const double omin[3] = {hdr->omin[0], hdr->omin[1], hdr->omin[2]};
+  const uint32_t per_axis = use_tab ? (2u << D) : 0u;
+  const bool fast = allow_fast && use_tab && hdr->margin_cells < 0.5f;
+  int J = fast ? hdr->jump_level : 0;
+
+  // LDS carve: luts (2 KiB) | centre tables | jump table | node words
+  float* lut_h = reinterpret_cast<float*>(smem);
+  float* lut_s = lut_h + 256;
+  float* tab = lut_s + 256;
+  uint32_t used = 2048u + 3u * per_axis * 4u;
+  used = (used + 15u) & ~15u;
+  uint32_t jump_bytes = J > 0 ? (2u << (3 * J)) : 0u;
+  if ((size_t)used + jump_bytes + (size_t)n_words * 4u > (size_t)lds_bytes) {  // keep the node words in LDS first
+    J = 0;
+    jump_bytes = 0;
+  }
+  uint16_t* ljump = reinterpret_cast<uint16_t*>(smem + used);
+  used += jump_bytes;
+  uint32_t* lwords = reinterpret_cast<uint32_t*>(smem + used);
+  const bool words_in_lds = (size_t)used + (size_t)n_words * 4u <= (size_t)lds_bytes;
+
+  for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
+    lut_h[i] = (float)i / 180.0f;
+    lut_s[i] = (float)i / 255.0f;
+  }
+  for (uint32_t i = threadIdx.x; i < 3u * per_axis; i += blockDim.x) tab[i] = d.centers[i];
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(d.jump);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(ljump);
+    for (uint32_t i = threadIdx.x; i < jump_bytes / 4u; i += blockDim.x) dst[i] = src[i];
+  }
+  if (words_in_lds)
+    for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) lwords[i] = d.words[i];
+  __syncthreads();
+
+  LikCtx cx;
+  cx.words = words_in_lds ? lwords : d.words;
+  cx.tab = tab;
+  cx.per_axis = per_axis;
+  cx.lut_h = lut_h;
+  cx.lut_s = lut_s;
+  cx.jump = ljump;
+  cx.J = J;
+  cx.lvlJ_start = J > 0 ? hdr->lvl_start[J] : 0u;
+  cx.margin = hdr->margin_cells;
+  cx.ominx = hdr->ominf[0];
+  cx.ominy = hdr->ominf[1];
+  cx.ominz = hdr->ominf[2];
+  cx.inv_res = hdr->inv_res;
+  cx.ncell = (float)(1u << (D > 0 ? D : 0));
+  if (fast)
+    likelihood_items<true, true, DEBUG_NN>(prm, d, cx, n_particles, D, n_crop, omin);
+  else if (use_tab)
+    likelihood_items<true, false, DEBUG_NN>(prm, d, cx, n_particles, D, n_crop, omin);
+  else
+    likelihood_items<false, false, DEBUG_NN>(prm, d, cx, n_particles, D, n_crop, omin);
+}
+
+static int g_allow_fast = -1;
+
+void pftk_likelihood(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, bool debug_nn,
+                     int num_cus) {
+  static bool attr_set = false;
+  uint32_t lds = (uint32_t)pftk_max_lds_bytes();
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_likelihood<false>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_likelihood<true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  if (g_allow_fast < 0) {  // PFT_GENERIC_DESCENT=1: all-generic descent (A/B and parity cross-check)
+    const char* e = getenv("PFT_GENERIC_DESCENT");
+    g_allow_fast = (e && e[0] == '1') ? 0 : 1;
+  }
+  uint32_t items = n_particles * p.nchunk;
+  uint32_t grid = (uint32_t)num_cus;
+  uint32_t need = (items + (PFT_LIK_THREADS / 64) - 1) / (PFT_LIK_THREADS / 64);
+  if (need == 0) need = 1;
+  if (grid > need) grid = need;
+  if (debug_nn)
+    hipLaunchKernelGGL(k_likelihood<true>, dim3(grid), dim3(PFT_LIK_THREADS), lds, s, p, d, n_particles, lds,
+                       g_allow_fast);
+  else
+    hipLaunchKernelGGL(k_likelihood<false>, dim3(grid), dim3(PFT_LIK_THREADS), lds, s, p, d, n_particles, lds,
+                       g_allow_fast);
+}

@@ -1,0 +1,475 @@
+// pft_octree.hip -- A5: search::Octree(res).setInputCloud(cropped) == OctreePointCloud::
+// addPointsFromInputCloud (PCL 1.8.0 octree/impl/octree_pointcloud.hpp), rebuilt every iteration.
+//
+// One 1024-thread workgroup (the build is a chain of short dependent phases; per-point state lives in
+// registers and the node words in LDS, so a phase costs a barrier, not an HBM round trip):
+//   1. replay of the insertion-order-dependent bounding-box growth (adoptBoundingBoxToPoint): rounds of
+//      "first point outside the current box" (parallel min-index search) + the serial growth steps
+//   2. key of every point in the final key frame (insertion-time key + later root shifts)
+//   3. top-down levels: atomicOr of child bits into the parent's mask, exclusive scan of popcounts ->
+//      child_base; children of a node are contiguous and ordered by child index
+//   4. leaves: counts -> starts (+ sentinel); points ranked by insertion index inside their leaf
+//      (OctreeContainerPointIndices keeps push_back order, and the leaf scan keeps the first minimum)
+//   5. per-level per-axis voxel-centre tables (genVoxelCenterFromOctreeKey), double -> float
+// Output in HBM: words[], leaf_pts[], leaf_order[], centers[], header.
+#include "pft_device_utils.h"
+
+#define STAMP(k) do { if (threadIdx.x == 0) d.hdr->ticks[k] = wall_clock64(); } while (0)
+
+struct BuildSh {
+  double mn[3], mx[3];
+  int depth, ngrow;
+  uint32_t cur, err, carry;
+  int jump;
+  uint32_t u32s[20];
+  uint32_t gidx[PFT_MAX_GROW], gshift[PFT_MAX_GROW], gold[PFT_MAX_GROW];
+  double gmin[PFT_MAX_GROW + 1][3];
+  uint32_t lvl[PFT_MAX_DEPTH + 3];
+};
+
+// first point: box = p +- res/2, then getKeyBitSize() pads it to depth 1 (side 2*res - eps)
+__device__ void box_init(BuildSh& S, float4 p0, double res) {
+  const double epsd = (double)FLT_EPSILON;
+  double lo[3] = {(double)p0.x - res / 2, (double)p0.y - res / 2, (double)p0.z - res / 2};
+  double hi[3] = {(double)p0.x + res / 2, (double)p0.y + res / 2, (double)p0.z + res / 2};
+  unsigned mk = 0;
+  for (int a = 0; a < 3; a++) {
+    unsigned k = (unsigned)((hi[a] - lo[a]) / res);
+    mk = k > mk ? k : mk;
+  }
+  unsigned mv = mk > 2u ? mk : 2u;
+  double l2 = log((double)mv) / log(2.0);
+  unsigned dep = (unsigned)ceil(l2 - (double)FLT_EPSILON);
+  if (dep > 32u) dep = 32u;
+  double side = (double)(1u << dep) * res - epsd;
+  for (int a = 0; a < 3; a++) {
+    double over = (side - (hi[a] - lo[a])) / 2.0;
+    S.mn[a] = lo[a] - over;
+    S.mx[a] = hi[a] + over;
+    S.gmin[0][a] = S.mn[a];
+  }
+  S.depth = (int)dep;
+}
+
+// adoptBoundingBoxToPoint for one violating point: new root above the old one until the point fits;
+// axes without an upper violation extend downwards
+__device__ void box_grow(BuildSh& S, float4 p, uint32_t idx, double res) {
+  const double epsd = (double)FLT_EPSILON;
+  for (;;) {
+    bool lx = p.x < S.mn[0], ly = p.y < S.mn[1], lz = p.z < S.mn[2];
+    bool ux = p.x >= S.mx[0], uy = p.y >= S.mx[1], uz = p.z >= S.mx[2];
+    if (!(lx || ly || lz || ux || uy || uz)) break;
+    int g = S.ngrow;
+    if (g >= PFT_MAX_GROW || S.depth >= PFT_MAX_DEPTH) {
+      S.err |= 2u;
+      break;
+    }
+    double side = (double)(1u << S.depth) * res;
+    S.gidx[g] = idx;
+    S.gshift[g] = (ux ? 0u : 1u) | (uy ? 0u : 2u) | (uz ? 0u : 4u);
+    S.gold[g] = (uint32_t)S.depth;
+    if (!ux) S.mn[0] -= side;
+    if (!uy) S.mn[1] -= side;
+    if (!uz) S.mn[2] -= side;
+    S.depth = S.depth + 1;
+    side = (double)(1u << S.depth) * res - epsd;
+    S.mx[0] = S.mn[0] + side;
+    S.mx[1] = S.mn[1] + side;
+    S.mx[2] = S.mn[2] + side;
+    S.gmin[g + 1][0] = S.mn[0];
+    S.gmin[g + 1][1] = S.mn[1];
+    S.gmin[g + 1][2] = S.mn[2];
+    S.ngrow = g + 1;
+  }
+}
+
+__device__ __forceinline__ bool box_violates(float x, float y, float z, const double* mn, const double* mx) {
+  return (x < mn[0]) || (y < mn[1]) || (z < mn[2]) || (x >= mx[0]) || (y >= mx[1]) || (z >= mx[2]);
+}
+
+// K points per thread (i = tid + j*1024); COORDS: keep xyz in registers across the rounds
+template <int K, bool COORDS>
+__device__ __forceinline__ void box_replay(BuildSh& S, const float4* __restrict__ pts, uint32_t n, double res) {
+  const uint32_t tid = threadIdx.x;
+  float px[COORDS ? K : 1], py[COORDS ? K : 1], pz[COORDS ? K : 1];
+  float lmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, lmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+#pragma unroll
+  for (int j = 0; j < K; j++) {
+    uint32_t i = tid + j * PFT_BUILD_THREADS;
+    if (i < n) {
+      float4 p = pts[i];
+      if (COORDS) {
+        px[j] = p.x; py[j] = p.y; pz[j] = p.z;
+      }
+      lmn[0] = fminf(lmn[0], p.x); lmx[0] = fmaxf(lmx[0], p.x);
+      lmn[1] = fminf(lmn[1], p.y); lmx[1] = fmaxf(lmx[1], p.y);
+      lmn[2] = fminf(lmn[2], p.z); lmx[2] = fmaxf(lmx[2], p.z);
+    }
+    UNROLL_FENCE(j, 4);
+  }
+  for (;;) {
+    const uint32_t cur = S.cur;
+    const double mn[3] = {S.mn[0], S.mn[1], S.mn[2]};
+    const double mx[3] = {S.mx[0], S.mx[1], S.mx[2]};
+    uint32_t first = 0xffffffffu;
+    // thread-local box first: once it fits, none of this thread's points can violate
+    if (box_violates(lmn[0], lmn[1], lmn[2], mn, mx) || box_violates(lmx[0], lmx[1], lmx[2], mn, mx)) {
+#pragma unroll
+      for (int j = K - 1; j >= 0; j--) {
+        uint32_t i = tid + j * PFT_BUILD_THREADS;
+        if (i < n && i >= cur) {
+          float x, y, z;
+          if (COORDS) {
+            x = px[j]; y = py[j]; z = pz[j];
+          } else {
+            float4 p = pts[i];
+            x = p.x; y = p.y; z = p.z;
+          }
+          if (box_violates(x, y, z, mn, mx)) first = i;
+        }
+      }
+    }
+    first = block_reduce<uint32_t>(first, S.u32s, OpMinU(), 0xffffffffu);
+    if (first == 0xffffffffu) break;
+    if (tid == 0) {
+      box_grow(S, pts[first], first, res);
+      S.cur = first + 1;
+    }
+    __syncthreads();
+    if (S.err) break;
+  }
+}
+
+// generic replay: any n
+__device__ __forceinline__ void box_replay_generic(BuildSh& S, const float4* __restrict__ pts, uint32_t n, double res) {
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  for (;;) {
+    const uint32_t cur = S.cur;
+    const double mn[3] = {S.mn[0], S.mn[1], S.mn[2]};
+    const double mx[3] = {S.mx[0], S.mx[1], S.mx[2]};
+    uint32_t first = 0xffffffffu;
+    for (uint32_t i = cur + tid; i < n; i += nt) {
+      float4 p = pts[i];
+      if (box_violates(p.x, p.y, p.z, mn, mx)) {
+        first = i;
+        break;
+      }
+    }
+    first = block_reduce<uint32_t>(first, S.u32s, OpMinU(), 0xffffffffu);
+    if (first == 0xffffffffu) break;
+    if (tid == 0) {
+      box_grow(S, pts[first], first, res);
+      S.cur = first + 1;
+    }
+    __syncthreads();
+    if (S.err) break;
+  }
+}
+
+// ---- per-point state: registers (packed 10-bit keys, D <= 10) or HBM arrays (21-bit keys) ----
+template <int K>
+struct RegStore {
+  typedef uint32_t key_t;
+  static constexpr int B = 10;
+  uint32_t key[K], node[K];
+  __device__ RegStore(const PftDev&) {}
+  template <class F>
+  __device__ __forceinline__ void each(uint32_t n, F&& f) {
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      uint32_t i = threadIdx.x + j * PFT_BUILD_THREADS;
+      if (i < n) f(i, key[j], node[j]);
+      UNROLL_FENCE(j, 4);
+    }
+  }
+};
+
+struct GlobStore {
+  typedef unsigned long long key_t;
+  static constexpr int B = 21;
+  unsigned long long* key;
+  uint32_t* node;
+  __device__ GlobStore(const PftDev& d) : key(d.pt_key64), node(d.pt_node) {}
+  template <class F>
+  __device__ __forceinline__ void each(uint32_t n, F&& f) {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) f(i, key[i], node[i]);
+  }
+};
+
+template <class KT, int B>
+__device__ __forceinline__ uint32_t key_child(KT k, int bit) {
+  return (uint32_t)(((k >> (2 * B + bit)) & 1) << 2) | (uint32_t)(((k >> (B + bit)) & 1) << 1) |
+         (uint32_t)((k >> bit) & 1);
+}
+
+template <class Store>
+__device__ __forceinline__ void build_tree(const PftParams& prm, const PftDev& d, BuildSh& S, uint32_t n, uint32_t* lds_words,
+                           uint32_t lds_words_cap, uint32_t* lds_tmp, uint32_t* out_leaf_start,
+                           uint32_t* out_n_leaves) {
+  typedef typename Store::key_t key_t;
+  constexpr int B = Store::B;
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const float4* pts = d.crop_pts;
+  const double res = prm.res;
+  const int D = S.depth, ngrow = S.ngrow;
+  Store st(d);
+
+  // ---- keys: genOctreeKeyforPoint at insertion time, shifted into the final key frame ----
+  st.each(n, [&](uint32_t i, key_t& key, uint32_t& node) {
+    float4 p = pts[i];
+    int e = 0;
+    while (e < ngrow && S.gidx[e] <= i) e++;
+    uint32_t kx = (uint32_t)(((double)p.x - S.gmin[e][0]) / res);
+    uint32_t ky = (uint32_t)(((double)p.y - S.gmin[e][1]) / res);
+    uint32_t kz = (uint32_t)(((double)p.z - S.gmin[e][2]) / res);
+    for (int s = e; s < ngrow; s++) {
+      uint32_t sh = S.gshift[s], od = S.gold[s];
+      if (sh & 1u) kx += 1u << od;
+      if (sh & 2u) ky += 1u << od;
+      if (sh & 4u) kz += 1u << od;
+    }
+    d.pt_key[3 * (size_t)i + 0] = kx;  // kept for the debug hook pft_debug_get_point_keys
+    d.pt_key[3 * (size_t)i + 1] = ky;
+    d.pt_key[3 * (size_t)i + 2] = kz;
+    key = ((key_t)kx << (2 * B)) | ((key_t)ky << B) | (key_t)kz;
+    node = 0;
+  });
+
+  STAMP(2);
+  uint32_t* W = (lds_words && lds_words_cap >= 16) ? lds_words : d.words;
+  // direct-index table of the level-J nodes for the likelihood kernel's fast descent
+  const int J = (D >= 4 && D <= PFT_TABLE_MAX_DEPTH) ? (D - 1 < PFT_JUMP_MAX_LEVEL ? D - 1 : PFT_JUMP_MAX_LEVEL) : 0;
+  if (J > 0) {
+    uint32_t* jz = reinterpret_cast<uint32_t*>(d.jump);
+    for (uint32_t j = tid; j < (1u << (3 * J - 1)); j += nt) jz[j] = 0u;
+  }
+  if (tid == 0) {
+    W[0] = 0;
+    S.lvl[0] = 0;
+    S.lvl[1] = 1;
+    S.jump = J;
+  }
+  __syncthreads();
+
+  // ---- levels ----
+  for (int l = 0; l < D; l++) {
+    const int bit = D - 1 - l;
+    const uint32_t lvl_first = S.lvl[l];
+    st.each(n, [&](uint32_t, key_t& key, uint32_t& node) {
+      if (l > 0) {  // move to the level-l node chosen by the previous level's bits
+        uint32_t w = W[node];
+        uint32_t cp = key_child<key_t, B>(key, bit + 1);
+        node = (w >> 8) + __popc(w & 0xffu & ((1u << cp) - 1u));
+      }
+      if (l == J && J > 0) {  // every point of a node stores the same value
+        const uint32_t sh = (uint32_t)(D - J), mk = (1u << J) - 1u;
+        const uint32_t cx = (uint32_t)(key >> (2 * B + sh)) & mk, cy = (uint32_t)(key >> (B + sh)) & mk,
+                       cz = (uint32_t)(key >> sh) & mk;
+        d.jump[cx | (cy << J) | (cz << (2 * J))] = (uint16_t)(node - lvl_first + 1u);
+      }
+      atomicOr(&W[node], 1u << key_child<key_t, B>(key, bit));
+    });
+    __syncthreads();
+    // child_base: each thread owns a contiguous run of this level's nodes, one workgroup scan per level
+    const uint32_t ls = S.lvl[l], le = S.lvl[l + 1], nl = le - ls;
+    const uint32_t per = (nl + nt - 1) / nt;
+    const uint32_t a0 = ls + min(nl, tid * per), a1 = ls + min(nl, (tid + 1) * per);
+    uint32_t cnt = 0;
+    for (uint32_t nd = a0; nd < a1; nd++) cnt += __popc(W[nd] & 0xffu);
+    uint32_t total;
+    uint32_t base = le + block_excl_scan<uint32_t>(cnt, S.u32s, &total);
+    const uint32_t nend = le + total;
+    if (nend + 2 > d.max_words || nend >= (1u << 24)) {
+      if (tid == 0) S.err |= 1u;
+    } else {
+      for (uint32_t nd = a0; nd < a1; nd++) {
+        const uint32_t wv = W[nd];
+        W[nd] = wv | (base << 8);
+        base += __popc(wv & 0xffu);
+      }
+    }
+    if (tid == 0) S.lvl[l + 2] = nend;
+    __syncthreads();
+    if (S.err) break;
+    if (W != d.words && nend + 2 > lds_words_cap) {  // node words outgrew LDS: continue in HBM
+      for (uint32_t j = tid; j < le; j += nt) d.words[j] = W[j];
+      W = d.words;
+    }
+    for (uint32_t j = le + tid; j < nend; j += nt) W[j] = 0;
+    __syncthreads();
+  }
+  __syncthreads();
+  if (S.err || D <= 0) {
+    *out_leaf_start = 0;
+    *out_n_leaves = 0;
+    return;
+  }
+
+  // ---- leaves ----
+  STAMP(3);
+  const uint32_t leaf_start = S.lvl[D], n_leaves = S.lvl[D + 1] - leaf_start;
+  st.each(n, [&](uint32_t, key_t& key, uint32_t& node) {
+    uint32_t w = W[node];
+    uint32_t c = key_child<key_t, B>(key, 0);
+    uint32_t leaf = (w >> 8) + __popc(w & 0xffu & ((1u << c) - 1u));
+    node = leaf;
+    key = (key_t)atomicAdd(&W[leaf], 1u);  // arrival slot inside the leaf (the key is no longer needed)
+  });
+  __syncthreads();
+  {
+    const uint32_t per = (n_leaves + nt - 1) / nt;
+    const uint32_t a0 = leaf_start + min(n_leaves, tid * per), a1 = leaf_start + min(n_leaves, (tid + 1) * per);
+    uint32_t cnt = 0;
+    for (uint32_t nd = a0; nd < a1; nd++) cnt += W[nd];
+    uint32_t total;
+    uint32_t start = block_excl_scan<uint32_t>(cnt, S.u32s, &total);
+    for (uint32_t nd = a0; nd < a1; nd++) {
+      const uint32_t c = W[nd];
+      W[nd] = start;
+      start += c;
+    }
+  }
+  if (tid == 0) W[leaf_start + n_leaves] = n;  // sentinel: count(leaf j) = start[j+1] - start[j]
+  __syncthreads();
+  STAMP(4);
+  uint32_t* TMP = lds_tmp ? lds_tmp : d.pt_tmp;
+  st.each(n, [&](uint32_t i, key_t& key, uint32_t& node) { TMP[W[node] + (uint32_t)key] = i; });
+  __syncthreads();
+  STAMP(5);
+  st.each(n, [&](uint32_t i, key_t&, uint32_t& node) {
+    const uint32_t s = W[node], e = W[node + 1];
+    uint32_t rank = 0;
+    for (uint32_t k = s; k < e; k++) rank += TMP[k] < i ? 1u : 0u;
+    d.leaf_order[s + rank] = i;
+    d.leaf_pts[s + rank] = pts[i];
+  });
+  STAMP(6);
+  const uint32_t n_words = leaf_start + n_leaves + 1;
+  if (W != d.words)
+    for (uint32_t j = tid; j < n_words; j += nt) d.words[j] = W[j];
+  *out_leaf_start = leaf_start;
+  *out_n_leaves = n_leaves;
+}
+
+template <int K>
+__device__ __forceinline__ void build_regs(const PftParams& prm, const PftDev& d, BuildSh& S, uint32_t n, uint32_t* lds_words,
+                           uint32_t cap, uint32_t* lds_tmp, uint32_t* ls, uint32_t* nl, int* path) {
+  box_replay<K, (K <= 16)>(S, d.crop_pts, n, prm.res);
+  __syncthreads();
+  STAMP(1);
+  if (S.err) return;
+  if (S.depth <= RegStore<K>::B) {
+    *path = 1;
+    build_tree<RegStore<K>>(prm, d, S, n, lds_words, cap, lds_tmp, ls, nl);
+  } else {
+    build_tree<GlobStore>(prm, d, S, n, lds_words, cap, lds_tmp, ls, nl);
+  }
+}
+
+__global__ __launch_bounds__(PFT_BUILD_THREADS) void k_octree_build(PftParams prm, PftDev d, uint32_t lds_bytes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ BuildSh S;
+  PftHeader* hdr = d.hdr;
+  const uint32_t n = hdr->n_crop;
+  const uint32_t tid = threadIdx.x;
+
+  STAMP(0);
+  if (tid == 0) {
+    S.err = 0;
+    S.ngrow = 0;
+    S.depth = 0;
+    S.cur = 1;
+    if (n > 0) box_init(S, d.crop_pts[0], prm.res);
+  }
+  __syncthreads();
+
+  // LDS carve: [tmp list: n words, if it leaves >= 2/3 for the nodes][node words]
+  uint32_t* lds_u = reinterpret_cast<uint32_t*>(smem);
+  const uint32_t lds_words_total = lds_bytes / 4u;
+  uint32_t* lds_tmp = nullptr;
+  uint32_t tmp_words = 0;
+  if ((size_t)n * 3u <= lds_words_total) {
+    lds_tmp = lds_u;
+    tmp_words = (n + 3u) & ~3u;
+  }
+  uint32_t* lds_words = lds_u + tmp_words;
+  const uint32_t cap = lds_words_total - tmp_words;
+
+  uint32_t leaf_start = 0, n_leaves = 0;
+  int path = 0;
+  if (n > 0) {
+    if (n <= 4u * PFT_BUILD_THREADS) build_regs<4>(prm, d, S, n, lds_words, cap, lds_tmp, &leaf_start, &n_leaves, &path);
+    else if (n <= 8u * PFT_BUILD_THREADS) build_regs<8>(prm, d, S, n, lds_words, cap, lds_tmp, &leaf_start, &n_leaves, &path);
+    else if (n <= 16u * PFT_BUILD_THREADS) build_regs<16>(prm, d, S, n, lds_words, cap, lds_tmp, &leaf_start, &n_leaves, &path);
+    else if (n <= 32u * PFT_BUILD_THREADS) build_regs<32>(prm, d, S, n, lds_words, cap, lds_tmp, &leaf_start, &n_leaves, &path);
+    else {
+      box_replay_generic(S, d.crop_pts, n, prm.res);
+      __syncthreads();
+      if (!S.err) build_tree<GlobStore>(prm, d, S, n, lds_words, cap, lds_tmp, &leaf_start, &n_leaves);
+    }
+  }
+  __syncthreads();
+  STAMP(7);
+  const int D = S.depth;
+  const bool ok = n > 0 && !S.err && D > 0;
+
+  // ---- voxel-centre tables: centre(level l, key k) = (float)((k + 0.5) * res*2^(D-l) + min) ----
+  const int use_table = (ok && D <= PFT_TABLE_MAX_DEPTH) ? 1 : 0;
+  if (use_table) {
+    const uint32_t per_axis = (2u << D);  // entry 2^l - 2 + k for level l = 1..D, key k
+    for (uint32_t e = tid; e < 3u * per_axis; e += blockDim.x) {
+      uint32_t a = e / per_axis, r = e % per_axis;
+      if (r + 2 >= per_axis) {
+        d.centers[e] = 0.0f;
+        continue;
+      }
+      uint32_t l = 31u - __clz(r + 2u);
+      uint32_t k = r + 2u - (1u << l);
+      double vs = prm.res * (double)(1u << (D - (int)l));
+      d.centers[e] = (float)(((double)k + 0.5) * vs + S.mn[a]);
+    }
+  }
+  STAMP(8);
+  if (tid == 0) {
+    hdr->error = S.err;
+    hdr->depth = D;
+    hdr->use_table = use_table;
+    hdr->n_grow = S.ngrow;
+    hdr->build_path = path;
+    hdr->jump_level = (ok && use_table) ? S.jump : 0;
+    {
+      // safety margin of the fast descent (DESIGN.md "fast descent"): float rounding of the voxel centres
+      // (<= ulp(max |coordinate|)) and of the squared-distance sums (<= 40 u s_top) can only reorder two
+      // children when the query is this close to a cell face
+      double maxabs = 0.0;
+      for (int a = 0; a < 3; a++) maxabs = fmax(maxabs, fmax(fabs(S.mn[a]), fabs(S.mx[a])));
+      const double eta = maxabs * 1.1920928955078125e-07;
+      const double s_top = prm.res * (double)(1u << (D > 0 ? D - 1 : 0));
+      const double E = 9.0 * eta + 40.0 * 5.9604644775390625e-08 * s_top;
+      double mc = 2.0 * E / prm.res + 1.0e-3;
+      hdr->margin_cells = (float)(mc < 0.25 ? mc : 1.0);  // >= 0.5: fast descent never taken
+      for (int a = 0; a < 3; a++) hdr->ominf[a] = (float)S.mn[a];
+      hdr->inv_res = (float)(1.0 / prm.res);
+    }
+    hdr->n_leaves = ok ? n_leaves : 0;
+    hdr->leaf_start = ok ? leaf_start : 0;
+    hdr->n_words = ok ? leaf_start + n_leaves + 1 : 0;
+    for (int a = 0; a < 3; a++) {
+      hdr->omin[a] = n > 0 ? S.mn[a] : 0.0;
+      hdr->omax[a] = n > 0 ? S.mx[a] : 0.0;
+    }
+    for (int l = 0; l <= D + 1 && l < PFT_MAX_DEPTH + 3; l++) hdr->lvl_start[l] = S.lvl[l];
+  }
+}
+
+void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d) {
+  static bool attr_set = false;
+  // static LDS of the kernel (BuildSh) is ~2.6 KB: leave 4 KB out of the dynamic request
+  const uint32_t lds = ((uint32_t)pftk_max_lds_bytes() - 4096u) & ~15u;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_octree_build), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_octree_build, dim3(1), dim3(PFT_BUILD_THREADS), lds, s, p, d, lds);
+}

@@ -1,0 +1,33 @@
+"""Distribution of descent work in the likelihood kernel (debug variant) on the steady-state workload."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pcl_tracking_amd import scene, tracker  # noqa: E402
+
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+model = scene.make_model(2048)
+cloud = scene.make_scene(50000)
+t = tracker.make_reference_tracker(particle_num=P, seed=1)
+t.setReferenceCloud(model)
+t.setTrans(scene.initial_trans())
+t.setInputCloud(cloud)
+for i in range(frames):
+    t.compute()
+p = t.getParticles()[:1024]
+st = t.evalWeights(p, want_nn=True)
+d = np.zeros(32, np.uint64)
+t._check(t._L.pft_debug_get_descent_stats(t._h, d.ctypes.data_as(C.c_void_p)))
+d = d.astype(np.float64)
+q = d[:11].sum()
+print("crop", len(st["crop_idx"]), "depth", st["octree_depth"], "leaves", st["n_leaves"], "words", st["n_words"],
+      "kbar", st["scan_points"] / max(1, st["scan_queries"]))
+print("queries by #generic levels:", (d[:11] / q).round(4), "mean", (d[:11] * np.arange(11)).sum() / q)
+print("jump used:", d[11] / q)
+wi = d[12]
+print("per wave-iteration: max generic %.2f  max fast %.2f  max leaf %.2f" % (d[13] / wi, d[14] / wi, d[15] / wi))
+print("wave iterations by max generic:", (d[16:27] / wi).round(4))

@@ -1,0 +1,30 @@
+"""Phase breakdown of the two single-workgroup kernels (octree build, population) from the in-kernel
+wall-clock stamps (100 MHz).  Usage on the GPU box:  python tools/phase_ticks.py [P] [N]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pcl_tracking_amd import scene, tracker  # noqa: E402
+
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
+model = scene.make_model(2048)
+cloud = scene.make_scene(N, mode="organized" if N == 307200 else "voxel")
+t = tracker.make_reference_tracker(particle_num=P, seed=1)
+t.setReferenceCloud(model)
+t.setTrans(scene.initial_trans())
+t.setInputCloud(cloud)
+for i in range(10):
+    t.compute()
+t.synchronize()
+tk = np.zeros(32, np.uint64)
+t._check(t._L.pft_debug_get_ticks(t._h, tk.ctypes.data_as(C.c_void_p)))
+o = tk[:9].astype(np.int64)
+names = ["init", "replay", "keys", "levels", "leaf-count+scan", "leaf-scatter", "leaf-rank+gather", "flush", "tables"]
+print("octree phases (us):", dict(zip(names[1:], ((o[1:] - o[:-1]) / 100.0).round(2))), "total", (o[8] - o[0]) / 100.0)
+p = tk[16:22].astype(np.int64)
+names = ["load", "normalize", "mean", "alias-pass1", "alias-scan+pass2"]
+print("population phases (us):", dict(zip(names, ((p[1:] - p[:-1]) / 100.0).round(2))), "total", (p[5] - p[0]) / 100.0)
