@@ -57,7 +57,9 @@ typedef enum pft_status {
 typedef struct pft_config {
   uint32_t abi_version;        /* PFT_ABI_VERSION */
   int32_t device_id;           /* HIP device ordinal */
-  void* stream;                /* hipStream_t to enqueue on; NULL = the handle creates its own */
+  void* stream;                /* hipStream_t to enqueue on (used when stream_is_external != 0; the null
+                                  handle then means HIP's default stream) */
+  int32_t stream_is_external;  /* 0: the handle creates its own non-blocking stream */
   int32_t particle_num;        /* setParticleNum            :231   400 */
   int32_t iteration_num;       /* setIterationNum           :229   2 */
   double step_noise_cov[6];    /* setStepNoiseCovariance    :226   0.015^2 (x40 for r,p,y) */

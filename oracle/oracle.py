@@ -103,6 +103,8 @@ def lib():
     L.orc_tracker_eval_weights.restype = sz
     L.orc_tracker_stage_times.argtypes = [vp, vp]
     L.orc_tracker_set_matrix_override.argtypes = [vp, vp]
+    L.orc_tracker_set_bbox_override.argtypes = [vp, vp]
+    L.orc_tracker_set_bbox_only.argtypes = [vp, C.c_int]
     _lib = L
     return L
 
@@ -314,9 +316,23 @@ class Tracker:
         lib().orc_tracker_stage_times(self.h, _ptr(s))
         return s
 
-    def eval_weights(self, particles, want_nn=False, mats=None):
-        """mats: optional (P,3,4) or (P,4,4) float32 matrices overriding toEigenMatrix(particle)"""
+    def bbox_of(self, particles):
+        """calcBoundingBox over the transformed reference clouds of these particles:
+        x_min,x_max,y_min,y_max,z_min,z_max"""
         p = np.ascontiguousarray(particles, PARTICLE_DTYPE)
+        bbox = np.zeros(6, np.float64)
+        lib().orc_tracker_set_bbox_only(self.h, 1)
+        lib().orc_tracker_eval_weights(self.h, _ptr(p), len(p), None, None, None, None, 0, _ptr(bbox), None, None,
+                                       None, None)
+        lib().orc_tracker_set_bbox_only(self.h, 0)
+        return bbox
+
+    def eval_weights(self, particles, want_nn=False, mats=None, bbox=None):
+        """mats: optional (P,3,4) or (P,4,4) float32 matrices overriding toEigenMatrix(particle);
+        bbox: optional crop box overriding calcBoundingBox (sharded-path tests)"""
+        p = np.ascontiguousarray(particles, PARTICLE_DTYPE)
+        bb = None if bbox is None else np.ascontiguousarray(bbox, np.float64)
+        lib().orc_tracker_set_bbox_override(self.h, _ptr(bb))
         m16 = None
         if mats is not None:
             mats = np.asarray(mats, np.float32)
@@ -338,6 +354,7 @@ class Tracker:
         nc = lib().orc_tracker_eval_weights(self.h, _ptr(p), P, _ptr(raw), _ptr(nn_idx), _ptr(nn_d2), _ptr(crop), N,
                                             _ptr(bbox), C.byref(depth), _ptr(ob), C.byref(sq), C.byref(sp))
         lib().orc_tracker_set_matrix_override(self.h, None)
+        lib().orc_tracker_set_bbox_override(self.h, None)
         return dict(raw=raw, nn_idx=None if nn_idx is None else nn_idx.reshape(P, M),
                     nn_d2=None if nn_d2 is None else nn_d2.reshape(P, M), crop_idx=crop[:nc].copy(), bbox=bbox,
                     octree_depth=depth.value, octree_min=ob[:3].copy(), octree_max=ob[3:].copy(),

@@ -641,6 +641,8 @@ struct orc_tracker {
   size_t transed_cap;
   double stage[7];
   const float* mat_override; /* tests: P row-major 4x4 matrices used instead of toEigenMatrix(p) */
+  const double* bbox_override; /* tests: x_min,x_max,y_min,y_max,z_min,z_max used instead of calcBoundingBox */
+  int bbox_only;               /* tests: stop after calcBoundingBox */
 };
 
 orc_tracker_t* orc_tracker_create(const orc_config_t* c) {
@@ -695,6 +697,8 @@ int orc_tracker_set_particles(orc_tracker_t* t, const orc_particle_t* p, size_t 
 
 double orc_tracker_fit_ratio(const orc_tracker_t* t) { return t->fit_ratio; }
 void orc_tracker_set_matrix_override(orc_tracker_t* t, const float* m16) { t->mat_override = m16; }
+void orc_tracker_set_bbox_override(orc_tracker_t* t, const double* bbox6) { t->bbox_override = bbox6; }
+void orc_tracker_set_bbox_only(orc_tracker_t* t, int on) { t->bbox_only = on; }
 void orc_tracker_stage_times(const orc_tracker_t* t, double s[7]) { memcpy(s, t->stage, sizeof(double) * 7); }
 
 static int n_threads(const orc_tracker_t* t) {
@@ -770,6 +774,11 @@ size_t orc_tracker_eval_weights(orc_tracker_t* t, const orc_particle_t* particle
   }
   if (bbox) {
     bbox[0] = x_min; bbox[1] = x_max; bbox[2] = y_min; bbox[3] = y_max; bbox[4] = z_min; bbox[5] = z_max;
+  }
+  if (t->bbox_only) return 0;
+  if (t->bbox_override) { /* tests of the sharded path: the box over ALL ranks' particles */
+    x_min = t->bbox_override[0]; x_max = t->bbox_override[1]; y_min = t->bbox_override[2];
+    y_max = t->bbox_override[3]; z_min = t->bbox_override[4]; z_max = t->bbox_override[5];
   }
   /* A4: cropInputPointCloud: PassThrough x, then y, then z */
   size_t N = t->N;

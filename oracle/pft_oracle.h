@@ -126,6 +126,10 @@ double orc_tracker_fit_ratio(const orc_tracker_t* t);
 /* tests only: use these P row-major 4x4 matrices instead of toEigenMatrix(particle) in eval_weights
  * (isolates the float descent/coherence arithmetic from libm-vs-ocml sin/cos ulp differences) */
 void orc_tracker_set_matrix_override(orc_tracker_t* t, const float* m16);
+/* tests of the particle-sharded host logic: crop with this box (the reduction over all ranks) instead of
+ * the box of the given particles; bbox_only stops eval_weights after calcBoundingBox */
+void orc_tracker_set_bbox_override(orc_tracker_t* t, const double* bbox6);
+void orc_tracker_set_bbox_only(orc_tracker_t* t, int on);
 
 /* Stage hook: the deterministic chain A1-A7 of one weight() call on explicit particles.
  * Any output pointer may be NULL.

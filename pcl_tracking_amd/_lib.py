@@ -22,6 +22,7 @@ class PftError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32), ("device_id", C.c_int32), ("stream", C.c_void_p),
+        ("stream_is_external", C.c_int32),
         ("particle_num", C.c_int32), ("iteration_num", C.c_int32),
         ("step_noise_cov", C.c_double * 6), ("initial_noise_cov", C.c_double * 6),
         ("initial_noise_mean", C.c_double * 6),

@@ -110,6 +110,7 @@ extern "C" void pft_config_default(pft_config* c) {
   c->abi_version = PFT_ABI_VERSION;
   c->device_id = 0;
   c->stream = nullptr;
+  c->stream_is_external = 0;
   c->particle_num = 400;
   c->iteration_num = 2;
   for (int k = 0; k < 6; k++) {
@@ -310,7 +311,7 @@ extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
   pft_tracker* t = new pft_tracker();
   t->cfg = *cfg;
   t->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (cfg->stream) {
+  if (cfg->stream_is_external) {
     t->stream = static_cast<hipStream_t>(cfg->stream);
   } else {
     if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) {

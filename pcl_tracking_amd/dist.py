@@ -97,16 +97,36 @@ class ShardedFilter:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
+        # RCCL ("nccl") takes device tensors directly.  Under gloo (CPU tests, or several ranks sharing one
+        # GPU in the single-GPU rehearsal of tests/test_gpu_dist.py) device tensors are staged through the host.
+        self.stage = dist.is_initialized() and dist.get_backend(group) == "gloo" and phases.bbox6.is_cuda
+
+    def _all_reduce_max(self, t):
+        if self.stage:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+
+    def _all_gather(self, out, shard):
+        if self.stage:
+            ho, hs = torch.empty(out.shape, dtype=out.dtype), shard.cpu()
+            dist.all_gather_into_tensor(ho, hs, group=self.group)
+            out.copy_(ho)
+        else:
+            dist.all_gather_into_tensor(out, shard, group=self.group)
+
     def compute(self):
         p = self.p
         p.begin_frame()
         for it in range(p.iteration_num):
             p.phase_a(it)
             if self.world > 1:
-                dist.all_reduce(p.bbox6, op=dist.ReduceOp.MAX, group=self.group)
+                self._all_reduce_max(p.bbox6)
             p.phase_b()
             if self.world > 1:
-                dist.all_gather_into_tensor(p.gathered, p.shard, group=self.group)
+                self._all_gather(p.gathered, p.shard)
             else:
                 p.gathered.copy_(p.shard)
             p.phase_c()

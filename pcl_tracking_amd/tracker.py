@@ -80,6 +80,7 @@ class ParticleFilterTracker:
         self._L.pft_config_default(C.byref(self._cfg))
         self._cfg.device_id = device_id
         self._cfg.stream = stream
+        self._cfg.stream_is_external = 0 if stream is None else 1  # 0 is a valid handle: the default stream
         self._cfg.seed = seed
         self._cfg.rank = rank
         self._cfg.world_size = world_size

@@ -1,0 +1,115 @@
+"""GPU checks of the particle-sharded path (pft_dist_* phases + pcl_tracking_amd/dist.py).
+
+The 8-GPU run belongs to the driver; what can be verified on one MI355X:
+  * world_size 1: the phase API reproduces pft_compute exactly;
+  * world_size 2 rehearsal: two processes share cuda:0 and exchange through gloo (RCCL refuses two ranks on
+    one device), so the sharded kernels run with id_offset != 0, P_local != P_total and a gathered
+    population buffer; result must equal the single-handle tracker bit for bit, and the oracle within 1e-4.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from pcl_tracking_amd import scene
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ("x", "y", "z", "roll", "pitch", "yaw")
+
+
+def _data():
+    return scene.make_model(1024), scene.make_scene(50000)[:20000]
+
+
+def _single(P, frames, seed):
+    from pcl_tracking_amd import tracker
+
+    model, cloud = _data()
+    t = tracker.make_reference_tracker(particle_num=P, seed=seed)
+    t.setReferenceCloud(model)
+    t.setTrans(scene.initial_trans())
+    t.setInputCloud(cloud)
+    out = []
+    for f in range(frames):
+        t.compute()
+        out.append(t.getResult().copy())
+    return out, t.getParticles()
+
+
+def test_phase_api_world_size_one_equals_compute():
+    import torch
+
+    from pcl_tracking_amd.dist import HipPhases, ShardedFilter
+
+    P, frames = 2048, 3
+    want, want_p = _single(P, frames, 5)
+    model, cloud = _data()
+    ph = HipPhases(P, 0, 1, torch.device("cuda", 0), seed=5)
+    ph.set_reference(model)
+    ph.set_trans(scene.initial_trans())
+    ph.set_input(cloud)
+    sf = ShardedFilter(ph)
+    for f in range(frames):
+        sf.compute()
+        assert sf.getResult().tobytes() == want[f].tobytes()
+    np.testing.assert_array_equal(sf.getParticles().view(np.float32), want_p.view(np.float32))
+
+
+def _worker(rank, world, port, outdir, P, frames, seed):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pcl_tracking_amd.dist import HipPhases, ShardedFilter
+
+    model, cloud = _data()
+    ph = HipPhases(P, rank, world, torch.device("cuda", 0), seed=seed)
+    ph.set_reference(model)
+    ph.set_trans(scene.initial_trans())
+    ph.set_input(cloud)
+    sf = ShardedFilter(ph)
+    res = []
+    for f in range(frames):
+        sf.compute()
+        res.append(np.frombuffer(sf.getResult().tobytes(), np.float32).copy())
+    np.save(os.path.join(outdir, "res%d.npy" % rank), np.stack(res))
+    np.save(os.path.join(outdir, "part%d.npy" % rank), sf.getParticles().view(np.float32).reshape(-1, 8))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_rehearsal_on_one_gpu(tmp_path, orc, world):
+    import torch.multiprocessing as mp
+
+    P, frames, seed = 2048, 3, 9
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), P, frames, seed), nprocs=world, join=True)
+    want, want_p = _single(P, frames, seed)
+    for r in range(world):
+        got = np.load(tmp_path / ("res%d.npy" % r))
+        for f in range(frames):
+            assert got[f].tobytes() == want[f].tobytes(), (r, f)
+        np.testing.assert_array_equal(np.load(tmp_path / ("part%d.npy" % r)),
+                                      want_p.view(np.float32).reshape(-1, 8))
+    # and against the CPU oracle
+    model, cloud = _data()
+    o = orc.Tracker(orc.default_config(particle_num=P, seed=seed, threads=0, emulate_pcl_alloc=0))
+    o.set_reference(model)
+    o.set_trans(scene.initial_trans())
+    o.set_input(cloud)
+    for f in range(frames):
+        o.compute()
+        ro = o.get_result()
+        for k in KEYS:
+            assert abs(float(want[f][k]) - float(ro[k])) < 1e-4
