@@ -52,5 +52,29 @@ def build(force=False, verbose=False, extra_flags=()):
     return LIB
 
 
+EXAMPLE_SRC = os.path.join(_HERE, "examples", "auto_tracking_amd.cpp")
+EXAMPLE_BIN = os.path.join(OUT_DIR, "auto_tracking_amd")
+
+
+def build_example(force=False, verbose=False):
+    """the ROS-free C++ driver (host side in the reference's language) over the header-only mirror of the
+    PCL classes and the C-ABI library"""
+    lib = build()
+    deps = [EXAMPLE_SRC, os.path.join(_HERE, "include", "pft", "particle_filter_tracker.hpp"), lib]
+    if not force and os.path.exists(EXAMPLE_BIN) and all(os.path.getmtime(d) <= os.path.getmtime(EXAMPLE_BIN) for d in deps):
+        return EXAMPLE_BIN
+    root = os.path.dirname(_HERE)
+    cmd = [hipcc(), "-std=c++17", "-O2", "-Wall", "-I", os.path.join(root, "include"), "-I", os.path.join(_HERE, "include"),
+           EXAMPLE_SRC, "-o", EXAMPLE_BIN, "-L", OUT_DIR, "-lpft_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("example build failed")
+    return EXAMPLE_BIN
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_example(force="--force" in sys.argv, verbose=True))

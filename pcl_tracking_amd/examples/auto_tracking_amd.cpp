@@ -1,0 +1,155 @@
+// auto_tracking_amd.cpp -- the tracking part of /root/reference/src/auto_tracking.cpp without ROS / VTK:
+// initialize_trackers() (:181-259), the "set object to track" step (:643-677: removeZeroPoints, centroid,
+// re-centre, setReferenceCloud, setTrans) and the per-frame loop (:688-697: setInputCloud, compute), followed
+// by what drawResult() does with the pose (:309-316: toEigenMatrix(getResult())).
+//
+//   auto_tracking_amd <model.bin> <frame0.bin> [frame1.bin ...] [--particles N] [--seed S]
+//
+// *.bin = raw arrays of 32-byte pcl::PointXYZRGBA records (what a binary PCD body of x y z rgba holds).
+// The model is the segmented object cluster in the camera frame; frames are already voxel-downsampled
+// (gridSampleApprox, :683, is the first "next" row of SURVEY.md 8f and not part of this path).
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pft/particle_filter_tracker.hpp"
+
+using namespace pft;
+using namespace pft::tracking;
+
+typedef PointXYZRGBA RefPointType;
+typedef ParticleXYZRPY ParticleT;
+typedef PointCloud<RefPointType> Cloud;
+typedef ParticleFilterTracker<RefPointType, ParticleT> ParticleFilter;
+
+static Cloud::Ptr load_bin(const char* path) {
+  Cloud::Ptr c(new Cloud());
+  FILE* f = std::fopen(path, "rb");
+  if (!f) {
+    std::fprintf(stderr, "cannot open %s\n", path);
+    return c;
+  }
+  std::fseek(f, 0, SEEK_END);
+  long sz = std::ftell(f);
+  std::fseek(f, 0, SEEK_SET);
+  c->points.resize((size_t)sz / sizeof(RefPointType));
+  if (std::fread(c->points.data(), sizeof(RefPointType), c->points.size(), f) != c->points.size()) c->points.clear();
+  std::fclose(f);
+  c->width = (uint32_t)c->points.size();
+  return c;
+}
+
+// auto_tracking.cpp:577-595
+static void removeZeroPoints(const Cloud& cloud, Cloud& result) {
+  for (size_t i = 0; i < cloud.points.size(); i++) {
+    const RefPointType& p = cloud.points[i];
+    if (!(std::fabs(p.x) < 0.01 && std::fabs(p.y) < 0.01 && std::fabs(p.z) < 0.01) && !std::isnan(p.x) &&
+        !std::isnan(p.y) && !std::isnan(p.z))
+      result.points.push_back(p);
+  }
+  result.width = (uint32_t)result.points.size();
+  result.height = 1;
+  result.is_dense = true;
+}
+
+int main(int argc, char** argv) {
+  std::vector<const char*> files;
+  int particles = 400;
+  uint64_t seed = 1;
+  for (int i = 1; i < argc; i++) {
+    if (!std::strcmp(argv[i], "--particles") && i + 1 < argc) particles = std::atoi(argv[++i]);
+    else if (!std::strcmp(argv[i], "--seed") && i + 1 < argc) seed = std::strtoull(argv[++i], nullptr, 10);
+    else files.push_back(argv[i]);
+  }
+  if (files.size() < 2) {
+    std::fprintf(stderr, "usage: %s <model.bin> <frame.bin>... [--particles N] [--seed S]\n", argv[0]);
+    return 2;
+  }
+
+  // ---- initialize_trackers(), auto_tracking.cpp:187-254 ----
+  std::vector<double> default_step_covariance(6, 0.015 * 0.015);
+  default_step_covariance[3] *= 40.0;
+  default_step_covariance[4] *= 40.0;
+  default_step_covariance[5] *= 40.0;
+  std::vector<double> initial_noise_covariance(6, 0.00001);
+  std::vector<double> default_initial_mean(6, 0.0);
+
+  std::shared_ptr<ParticleFilter> tracker_;
+  {
+    std::shared_ptr<ParticleFilterOMPTracker<RefPointType, ParticleT>> tracker(
+        new ParticleFilterOMPTracker<RefPointType, ParticleT>(16));
+    tracker_ = tracker;
+  }
+  tracker_->setTrans(Affine3f::Identity());
+  tracker_->setStepNoiseCovariance(default_step_covariance);
+  tracker_->setInitialNoiseCovariance(initial_noise_covariance);
+  tracker_->setInitialNoiseMean(default_initial_mean);
+  tracker_->setIterationNum(2);
+  tracker_->setParticleNum(particles);
+  tracker_->setResampleLikelihoodThr(0.00);
+  tracker_->setUseNormal(false);
+  tracker_->setSeed(seed);
+
+  ApproxNearestPairPointCloudCoherence<RefPointType>::Ptr coherence(
+      new ApproxNearestPairPointCloudCoherence<RefPointType>());
+  std::shared_ptr<DistanceCoherence<RefPointType>> distance_coherence(new DistanceCoherence<RefPointType>());
+  coherence->addPointCoherence(distance_coherence);
+  std::shared_ptr<HSVColorCoherence<RefPointType>> color_coherence(new HSVColorCoherence<RefPointType>());
+  color_coherence->setWeight(0.1);
+  coherence->addPointCoherence(color_coherence);
+  std::shared_ptr<search::Octree<RefPointType>> search(new search::Octree<RefPointType>(0.01));
+  coherence->setSearchMethod(search);
+  coherence->setMaximumDistance(0.1);
+  tracker_->setCloudCoherence(coherence);
+
+  // ---- "set object to track", auto_tracking.cpp:655-676 ----
+  Cloud::Ptr ref_cloud = load_bin(files[0]);
+  Cloud::Ptr nonzero_ref(new Cloud());
+  removeZeroPoints(*ref_cloud, *nonzero_ref);
+  if (nonzero_ref->empty()) {
+    std::fprintf(stderr, "empty model\n");
+    return 1;
+  }
+  double cx = 0, cy = 0, cz = 0;  // pcl::compute3DCentroid accumulates in the scalar type of the result (float)
+  {
+    float sx = 0, sy = 0, sz = 0;
+    for (const auto& p : nonzero_ref->points) {
+      sx += p.x;
+      sy += p.y;
+      sz += p.z;
+    }
+    cx = sx / (float)nonzero_ref->size();
+    cy = sy / (float)nonzero_ref->size();
+    cz = sz / (float)nonzero_ref->size();
+  }
+  Affine3f trans = Affine3f::Identity();
+  trans(0, 3) = (float)cx;
+  trans(1, 3) = (float)cy;
+  trans(2, 3) = (float)cz;
+  Cloud::Ptr transed_ref(new Cloud(*nonzero_ref));
+  for (auto& p : transed_ref->points) {  // transformPointCloud by trans.inverse(): a pure translation
+    p.x -= (float)cx;
+    p.y -= (float)cy;
+    p.z -= (float)cz;
+  }
+  tracker_->setReferenceCloud(transed_ref);
+  tracker_->setTrans(trans);
+  tracker_->setMinIndices((int)ref_cloud->points.size() / 2);
+
+  // ---- "track the object", auto_tracking.cpp:688-697, then drawResult :309-310 ----
+  for (size_t f = 1; f < files.size(); f++) {
+    Cloud::Ptr cloud_pass_downsampled_ = load_bin(files[f]);
+    tracker_->setInputCloud(cloud_pass_downsampled_);
+    tracker_->compute();
+    ParticleXYZRPY result = tracker_->getResult();
+    Affine3f transformation = tracker_->toEigenMatrix(result);
+    std::printf("frame %zu pose %.6f %.6f %.6f %.6f %.6f %.6f  t = [%.5f %.5f %.5f]\n", f, result.x, result.y,
+                result.z, result.roll, result.pitch, result.yaw, transformation(0, 3), transformation(1, 3),
+                transformation(2, 3));
+  }
+  return 0;
+}

@@ -1,0 +1,82 @@
+"""Generates tests/golden/*.npz from the CPU oracle on small seeded cases.
+
+These fixtures pin the ORACLE RESTATEMENT, not PCL: PCL 1.8.0 cannot be built or imported here and the
+reference ships no vectors for this path, so parity stays "unpinned" with respect to PCL.
+They exist so that (a) a change to the oracle is visible as a diff of committed data and (b) the GPU path
+is checked against fixed numbers as well as against a live oracle run.
+
+    python tests/golden/make_golden.py        # rewrites the fixtures
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import oracle as orc  # noqa: E402
+
+from pcl_tracking_amd import scene  # noqa: E402
+
+
+def particles_around(pose, n, seed, sig_t=0.015, sig_r=0.09):
+    rng = np.random.default_rng(seed)
+    p = np.zeros(n, scene.PARTICLE_DTYPE)
+    for k, name in enumerate(("x", "y", "z")):
+        p[name] = pose[k] + rng.normal(0, sig_t, n)
+    for k, name in enumerate(("roll", "pitch", "yaw")):
+        p[name] = pose[3 + k] + rng.normal(0, sig_r, n)
+    p["w"] = 1.0
+    p["weight"] = 1.0 / n
+    return p
+
+
+def case_eval(name, M, N, P, seed):
+    model = scene.make_model(M, seed=1000 + M)
+    cloud = scene.make_scene(50000)[:N]
+    t = orc.Tracker(orc.default_config(particle_num=P, seed=seed, threads=1, emulate_pcl_alloc=0))
+    t.set_reference(model)
+    t.set_trans(scene.initial_trans())
+    t.set_input(cloud)
+    p = particles_around(scene.model_gt_pose(), P, seed)
+    mats = np.stack([orc.get_transformation(*[q[k] for k in ("x", "y", "z", "roll", "pitch", "yaw")])[:3] for q in p])
+    ev = t.eval_weights(p, want_nn=True, mats=mats)
+    w, fit = orc.normalize_weights(ev["raw"])
+    a, q = orc.gen_alias_table(w)
+    pw = p.copy()
+    pw["weight"] = w
+    mean = orc.weighted_mean(pw)
+    np.savez_compressed(
+        os.path.join(HERE, name + ".npz"),
+        model=model.view(np.uint8), cloud=cloud.view(np.uint8), particles=p.view(np.float32).reshape(-1, 8),
+        mats=mats, raw=ev["raw"], nn_idx=ev["nn_idx"], nn_d2=ev["nn_d2"], crop_idx=ev["crop_idx"],
+        bbox=ev["bbox"], octree_depth=ev["octree_depth"], octree_min=ev["octree_min"], octree_max=ev["octree_max"],
+        weights=w, fit_ratio=fit, alias_a=a, alias_q=q, mean=np.frombuffer(mean.tobytes(), np.float32),
+        scan=np.array([ev["scan_queries"], ev["scan_points"]], np.uint64))
+    print(name, "crop", len(ev["crop_idx"]), "depth", ev["octree_depth"])
+
+
+def case_track(name, M, N, P, frames, seed):
+    model = scene.make_model(M, seed=2000 + M)
+    cloud = scene.make_scene(50000)[:N]
+    t = orc.Tracker(orc.default_config(particle_num=P, seed=seed, threads=1, emulate_pcl_alloc=0))
+    t.set_reference(model)
+    t.set_trans(scene.initial_trans())
+    t.set_input(cloud)
+    res = []
+    for f in range(frames):
+        assert t.compute() == 0
+        res.append(np.frombuffer(t.get_result().tobytes(), np.float32).copy())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), model=model.view(np.uint8), cloud=cloud.view(np.uint8),
+                        results=np.stack(res), particles=t.get_particles().view(np.float32).reshape(-1, 8),
+                        P=P, seed=seed)
+    print(name, "final", res[-1][:3])
+
+
+if __name__ == "__main__":
+    case_eval("eval_small", M=96, N=1500, P=24, seed=7)
+    case_eval("eval_ragged", M=257, N=4001, P=33, seed=8)
+    case_track("track_small", M=200, N=5000, P=200, frames=4, seed=12)

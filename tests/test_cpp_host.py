@@ -1,0 +1,79 @@
+"""The C++ host side (pcl_tracking_amd/include/pft/particle_filter_tracker.hpp + examples/auto_tracking_amd.cpp):
+the reference is C++, so the mirror of the PCL classes it drives is C++ too.  CPU: it compiles and links
+against the C-ABI library.  GPU: the ROS-free driver, fed a model cluster and frames as PCL-layout binary
+files, reports the same poses as the Python binding (both are thin layers over the same C ABI)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from pcl_tracking_amd import scene
+
+
+def test_cpp_mirror_compiles_and_links():
+    from pcl_tracking_amd import build
+
+    exe = build.build_example()
+    assert os.path.exists(exe) and os.access(exe, os.X_OK)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+
+
+def test_cpp_mirror_uses_the_reference_call_names():
+    """every tracker/coherence member the reference calls exists in the mirror"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "pcl_tracking_amd", "include", "pft", "particle_filter_tracker.hpp")).read()
+    for name in ("setTrans", "setStepNoiseCovariance", "setInitialNoiseCovariance", "setInitialNoiseMean",
+                 "setIterationNum", "setParticleNum", "setResampleLikelihoodThr", "setUseNormal", "setCloudCoherence",
+                 "getParticles", "getResult", "toEigenMatrix", "setReferenceCloud", "setMinIndices", "setInputCloud",
+                 "compute", "addPointCoherence", "setWeight", "setSearchMethod", "setMaximumDistance",
+                 "ParticleFilterOMPTracker", "ApproxNearestPairPointCloudCoherence", "DistanceCoherence",
+                 "HSVColorCoherence"):
+        assert name in hdr, name
+
+
+@pytest.mark.gpu
+def test_cpp_driver_matches_python_binding(tmp_path):
+    from pcl_tracking_amd import build, tracker
+
+    exe = build.build_example()
+    model = scene.make_model(512)
+    # the segmented cluster as create_model.cpp would hand it over: in the camera frame
+    cluster = model.copy()
+    off = np.array(scene.model_gt_pose()[:3], np.float32)
+    for k, name in enumerate(("x", "y", "z")):
+        cluster[name] = cluster[name] + off[k]
+    frames = [scene.make_scene(50000, obj_pose=scene.advance_pose(scene.GT_POSE, 3 * f))[:15000] for f in range(3)]
+    cluster.tofile(tmp_path / "model.bin")
+    paths = []
+    for i, fr in enumerate(frames):
+        fr.tofile(tmp_path / ("frame%d.bin" % i))
+        paths.append(str(tmp_path / ("frame%d.bin" % i)))
+    r = subprocess.run([exe, str(tmp_path / "model.bin")] + paths + ["--particles", "1000", "--seed", "6"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = [list(map(float, line.split("pose")[1].split("t =")[0].split())) for line in r.stdout.splitlines()
+           if line.startswith("frame")]
+    assert len(got) == 3
+    # the same steps in Python: float centroid (sequential float sums as the driver does), re-centre, track
+    s = np.zeros(3, np.float32)
+    for p in cluster:
+        s[0] += p["x"]
+        s[1] += p["y"]
+        s[2] += p["z"]
+    c = s / np.float32(len(cluster))
+    ref = cluster.copy()
+    for k, name in enumerate(("x", "y", "z")):
+        ref[name] = ref[name] - c[k]
+    trans = np.eye(4, dtype=np.float32)
+    trans[:3, 3] = c
+    t = tracker.make_reference_tracker(particle_num=1000, seed=6)
+    t.setReferenceCloud(ref)
+    t.setTrans(trans)
+    for f in range(3):
+        t.setInputCloud(frames[f])
+        t.compute()
+        res = t.getResult()
+        want = [float(res[k]) for k in ("x", "y", "z", "roll", "pitch", "yaw")]
+        np.testing.assert_allclose(got[f], want, atol=2e-6)

@@ -1,0 +1,101 @@
+"""Committed fixtures (tests/golden/*.npz, produced by tests/golden/make_golden.py from the oracle):
+CPU: the oracle still reproduces them bit for bit; GPU: the HIP path reproduces them through the C ABI.
+The fixtures pin the oracle restatement, not PCL (parity unpinned: tests/golden/README.md)."""
+import os
+
+import numpy as np
+import pytest
+
+from pcl_tracking_amd import scene
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KEYS = ("x", "y", "z", "roll", "pitch", "yaw")
+
+
+def load(name):
+    z = np.load(os.path.join(G, name + ".npz"))
+    d = {k: z[k] for k in z.files}
+    d["model"] = d["model"].view(scene.POINT_DTYPE)
+    d["cloud"] = d["cloud"].view(scene.POINT_DTYPE)
+    if "particles" in d:
+        d["particles"] = np.ascontiguousarray(d["particles"]).view(scene.PARTICLE_DTYPE).reshape(-1)
+    return d
+
+
+@pytest.mark.parametrize("name", ["eval_small", "eval_ragged"])
+def test_oracle_reproduces_eval_fixture(orc, name):
+    d = load(name)
+    t = orc.Tracker(orc.default_config(particle_num=len(d["particles"]), threads=1, emulate_pcl_alloc=0))
+    t.set_reference(d["model"])
+    t.set_trans(scene.initial_trans())
+    t.set_input(d["cloud"])
+    ev = t.eval_weights(d["particles"], want_nn=True, mats=d["mats"])
+    for k in ("raw", "nn_idx", "nn_d2", "crop_idx", "bbox", "octree_min", "octree_max"):
+        np.testing.assert_array_equal(ev[k], d[k], err_msg=k)
+    assert ev["octree_depth"] == int(d["octree_depth"])
+    w, fit = orc.normalize_weights(d["raw"])
+    np.testing.assert_array_equal(w, d["weights"])
+    a, q = orc.gen_alias_table(d["weights"])
+    np.testing.assert_array_equal(a, d["alias_a"])
+    np.testing.assert_array_equal(q, d["alias_q"])
+
+
+def test_oracle_reproduces_track_fixture(orc):
+    d = load("track_small")
+    t = orc.Tracker(orc.default_config(particle_num=int(d["P"]), seed=int(d["seed"]), threads=1, emulate_pcl_alloc=0))
+    t.set_reference(d["model"])
+    t.set_trans(scene.initial_trans())
+    t.set_input(d["cloud"])
+    for f in range(len(d["results"])):
+        assert t.compute() == 0
+        np.testing.assert_array_equal(np.frombuffer(t.get_result().tobytes(), np.float32), d["results"][f])
+    np.testing.assert_array_equal(t.get_particles().view(np.float32).reshape(-1, 8),
+                                  d["particles"].view(np.float32).reshape(-1, 8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["eval_small", "eval_ragged"])
+def test_gpu_matches_eval_fixture(name):
+    from pcl_tracking_amd import tracker
+
+    d = load(name)
+    P = len(d["particles"])
+    g = tracker.make_reference_tracker(particle_num=P)
+    g.setReferenceCloud(d["model"])
+    g.setTrans(scene.initial_trans())
+    g.setInputCloud(d["cloud"])
+    ev = g.evalWeights(d["particles"], want_nn=True)
+    # the GPU forms its matrices with double sin/cos rounded to float; the fixture's came from cosf/sinf
+    mats = g.debugPoseToMatrix(d["particles"])
+    same = np.all(mats.reshape(P, -1) == d["mats"].reshape(P, -1), axis=1)
+    assert same.mean() > 0.5
+    np.testing.assert_array_equal(ev["crop_idx"], d["crop_idx"])
+    assert ev["octree_depth"] == int(d["octree_depth"])
+    np.testing.assert_array_equal(ev["octree_min"], d["octree_min"])
+    np.testing.assert_array_equal(ev["nn_idx"][same], d["nn_idx"][same])  # bit-exact where the matrix is
+    np.testing.assert_array_equal(ev["nn_d2"][same], d["nn_d2"][same])
+    assert (ev["nn_idx"] == d["nn_idx"]).mean() > 0.999
+    np.testing.assert_allclose(ev["raw"], d["raw"], atol=1e-3, rtol=0)
+    w, fit = g.debugNormalize(d["raw"])
+    assert np.abs(w.view(np.int32) - d["weights"].view(np.int32)).max() <= 1
+    a, q = g.debugAlias(d["weights"])
+    np.testing.assert_array_equal(a, d["alias_a"])
+    np.testing.assert_allclose(q, d["alias_q"], atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_gpu_matches_track_fixture():
+    from pcl_tracking_amd import tracker
+
+    d = load("track_small")
+    g = tracker.make_reference_tracker(particle_num=int(d["P"]), seed=int(d["seed"]))
+    g.setReferenceCloud(d["model"])
+    g.setTrans(scene.initial_trans())
+    g.setInputCloud(d["cloud"])
+    for f in range(len(d["results"])):
+        g.compute()
+        r = g.getResult()
+        want = d["results"][f]
+        for i, k in enumerate(KEYS):
+            j = i if i < 3 else i + 1  # x,y,z,w,roll,pitch,yaw,weight
+            assert abs(float(r[k]) - float(want[j])) < 1e-4, (f, k)
