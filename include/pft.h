@@ -147,6 +147,9 @@ int pft_debug_get_ticks(pft_tracker* t, uint64_t* ticks32);
  * number of generic levels, [11] queries that used the jump table, [12] wave iterations, [13..15] sums of
  * the per-wave maxima of generic levels / fast levels / leaf size, [16..26] wave iterations by max generic */
 int pft_debug_get_descent_stats(pft_tracker* t, uint64_t* dbg32);
+/* timing experiments only: skip stages of the likelihood kernel (bit0 generic levels, bit1 leaf scan,
+ * bit2 coherence); results are wrong by construction while a mask is set */
+void pft_debug_set_ablate(int mask);
 int pft_debug_normalize(pft_tracker* t, float* w_inout, size_t n, double* fit_ratio);
 int pft_debug_alias(pft_tracker* t, const float* w, size_t n, int32_t* a, double* q);
 int pft_debug_weighted_mean(pft_tracker* t, const pft_particle* p, size_t n, pft_particle* out);

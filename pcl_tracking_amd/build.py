@@ -37,6 +37,7 @@ def needs_build():
 
 
 def build(force=False, verbose=False, extra_flags=()):
+    extra_flags = list(extra_flags) + os.environ.get("PFT_EXTRA_HIPCC_FLAGS", "").split()
     if not force and not needs_build():
         return LIB
     os.makedirs(OUT_DIR, exist_ok=True)

@@ -22,10 +22,15 @@
 #define PFT_MAX_DEPTH 30
 #define PFT_TABLE_MAX_DEPTH 10
 #define PFT_MAX_GROW 40
-#define PFT_JUMP_MAX_LEVEL 5     // 2^15 cells x u16 = 64 KiB of LDS in the likelihood kernel
+#define PFT_JUMP_MAX_LEVEL 4     // 2^12 cells x u16 = 8 KiB of LDS in the likelihood kernel
 #define PFT_REF_CHUNK 512        // reference points per likelihood work item
-#define PFT_BUILD_THREADS 512
-#define PFT_LIK_THREADS 1024
+#define PFT_BUILD_THREADS 1024
+#ifndef PFT_LIK_THREADS
+#define PFT_LIK_THREADS 1024   // likelihood workgroup size
+#endif
+#ifndef PFT_LIK_WGS_PER_CU
+#define PFT_LIK_WGS_PER_CU 2    // resident likelihood workgroups per CU (each gets 1/N of the LDS)
+#endif
 #define PFT_POP_THREADS 1024
 #define PFT_MAX_PARTICLES (64 * PFT_POP_THREADS)  // population kernel: <= 64 particles per thread
 

@@ -33,6 +33,8 @@ struct LikCtx {
   int J;
   uint32_t lvlJ_start;
   float margin, ominx, ominy, ominz, inv_res, ncell;
+  uint32_t leaf0;
+  const uint16_t* leaf16;  // LDS: start offsets of the leaves (+ sentinel)
 };
 
 __device__ __forceinline__ double rcp_nr(double x) {
@@ -56,10 +58,10 @@ __device__ __forceinline__ bool face_violation(uint32_t kx, uint32_t ky, uint32_
   return v;
 }
 
-template <bool USE_TAB, bool FAST, bool DEBUG_NN>
-__device__ __forceinline__ void likelihood_items(const PftParams& prm, const PftDev& d, const LikCtx& cx,
+template <bool USE_TAB, bool FAST, bool DEBUG_NN, bool LEAF16, typename WordPtr>
+__device__ __forceinline__ void likelihood_items(const PftParams& prm, const PftDev& d, const LikCtx& cx, WordPtr W,
                                                  uint32_t n_particles, int D, uint32_t n_crop,
-                                                 const double omin[3]) {
+                                                 const double omin[3], int abl) {
   const int lane = lane_id(), w = wave_id(), nw = blockDim.x >> 6;
   const uint32_t gw = blockIdx.x * nw + w, tw = gridDim.x * nw;
   const uint32_t M = prm.M, nchunk = prm.nchunk;
@@ -68,8 +70,6 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
   const double maxd2 = prm.maxd2;
   const double wd = prm.dist_w, whsv = prm.hsv_w;
   const float hw = prm.h_w, sw = prm.s_w, vw = prm.v_w;
-  const uint32_t* W = cx.words;
-
   for (uint32_t item = gw; item < n_items; item += tw) {
     const uint32_t pi = item / nchunk, ch = item % nchunk;
     float T[12];
@@ -77,8 +77,11 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
     double val = 0.0;
     unsigned long long st_q = 0, st_s = 0;
     const uint32_t jend = min(M, (ch + 1) * (uint32_t)PFT_REF_CHUNK);
-    for (uint32_t j = ch * PFT_REF_CHUNK + lane; j < jend; j += WAVE) {
-      const float4 r = d.ref_xyz[j];
+    const uint32_t j0 = ch * PFT_REF_CHUNK + lane;
+    float4 rnext = j0 < jend ? d.ref_xyz[j0] : make_float4(0, 0, 0, 0);
+    for (uint32_t j = j0; j < jend; j += WAVE) {
+      const float4 r = rnext;
+      if (j + WAVE < jend) rnext = d.ref_xyz[j + WAVE];  // next point's load overlaps this point's descent
       float qx, qy, qz;
       xform(T, r.x, r.y, r.z, qx, qy, qz);
       if (n_crop == 0) {  // empty target: PCL asserts; defined as "no correspondence"
@@ -91,7 +94,7 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
       }
       uint32_t node = 0, pkx = 0, pky = 0, pkz = 0;
       int lvl = 0;
-      int dbg_fast = 0, dbg_gen = 0, dbg_jump = 0;
+      int dbg_fast = 0, dbg_gen = 0, dbg_jump = 0, dbg_hard = 0;
       if (FAST) {
         // integer key of the query in leaf cells (float: error < 1e-4 cells, far inside the margin)
         const float tx = (qx - cx.ominx) * cx.inv_res, ty = (qy - cx.ominy) * cx.inv_res,
@@ -132,6 +135,10 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         pkx = kx >> up; pky = ky >> up; pkz = kz >> up;  // path key of `node` (zero at the root)
       }
       // ---- generic levels: exact float evaluation of the existing children ----
+      if ((abl & 1) && lvl < D) {  // timing ablation only (PFT_ABLATE): skip the generic levels
+        node = cx.leaf0;
+        lvl = D;
+      }
       for (; lvl < D; lvl++) {
         dbg_gen++;
         const uint32_t wv = W[node];
@@ -167,14 +174,27 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
             bc = c;
           }
         }
+        if (DEBUG_NN) {  // "hard" step: the per-axis nearest child (the ideal corner) does not exist
+          const uint32_t ideal = ((X1 < X0) ? 4u : 0u) | ((Y1 < Y0) ? 2u : 0u) | ((Z1 < Z0) ? 1u : 0u);
+          if (!((mask >> ideal) & 1u)) dbg_hard++;
+        }
         node = base + __popc(mask & ((1u << bc) - 1u));
         pkx = 2u * pkx + ((bc >> 2) & 1u);
         pky = 2u * pky + ((bc >> 1) & 1u);
         pkz = 2u * pkz + (bc & 1u);
       }
       // ---- leaf scan: first strictly-smaller wins (insertion order) ----
-      const uint32_t ls = W[node], le = W[node + 1];
-      float bd = INFINITY;
+      uint32_t ls, le;
+      if (LEAF16) {  // leaf starts as u16 in LDS (cropped clouds below 65536 points)
+        const uint32_t li = node - cx.leaf0;
+        ls = cx.leaf16[li];
+        le = cx.leaf16[li + 1u];
+      } else {
+        ls = W[node];
+        le = W[node + 1];
+      }
+      if (abl & 2) le = ls;
+      float bd = (abl & 2) ? 1.0e-3f : INFINITY;
       uint32_t bpos = ls;
       float4 bt = make_float4(0, 0, 0, 0);
       for (uint32_t pos = ls; pos < le; pos++) {
@@ -196,6 +216,7 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         // distribution of the descent work: per query and per wave (max over lanes)
         atomicAdd(&d.hdr->dbg[dbg_gen < 10 ? dbg_gen : 10], 1ull);
         atomicAdd(&d.hdr->dbg[11], (unsigned long long)dbg_jump);
+        atomicAdd(&d.hdr->dbg[27 + (dbg_hard < 4 ? dbg_hard : 4)], 1ull);
         int mg_ = dbg_gen, mf_ = dbg_fast, ml_ = (int)(le - ls);
         for (int o = 32; o > 0; o >>= 1) {
           mg_ = max(mg_, __shfl_xor(mg_, o));
@@ -211,7 +232,9 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         }
       }
       // ---- A7: gate + point coherences ----
-      if ((double)bd < maxd2) {
+      if (abl & 4) {
+        val += (double)bd;
+      } else if ((double)bd < maxd2) {
         // DistanceCoherence: Vector4f norm (SSE3 packet reduction (dx2+dy2)+(dz2+0)); 1/(1 + d*d*w)
         float ex = qx - bt.x, ey = qy - bt.y, ez = qz - bt.z;
         float n2 = (ex * ex + ey * ey) + ez * ez;
@@ -255,8 +278,9 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
 }
 
 template <bool DEBUG_NN>
-__global__ __launch_bounds__(PFT_LIK_THREADS) void k_likelihood(PftParams prm, PftDev d, uint32_t n_particles,
-                                                                uint32_t lds_bytes, int allow_fast) {
+__global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * PFT_LIK_WGS_PER_CU) / 256) void k_likelihood(PftParams prm, PftDev d, uint32_t n_particles,
+                                                                uint32_t lds_bytes, int flags) {
+  const int allow_fast = flags & 1, abl = flags >> 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const PftHeader* hdr = d.hdr;
   const int D = hdr->depth;
@@ -274,15 +298,22 @@ __global__ __launch_bounds__(PFT_LIK_THREADS) void k_likelihood(PftParams prm, P
   float* tab = lut_s + 256;
   uint32_t used = 2048u + 3u * per_axis * 4u;
   used = (used + 15u) & ~15u;
+  // node words: branch levels as u32; the leaf level (about 70 % of the words) as u16 start offsets when the
+  // cropped cloud has fewer than 65536 points
+  const uint32_t leaf_start = hdr->leaf_start, n_leaves = hdr->n_leaves;
+  const bool leaf16 = n_crop > 0 && n_crop < 65536u;
+  const uint32_t branch_bytes = leaf16 ? leaf_start * 4u : n_words * 4u;
+  const uint32_t leaf_bytes = leaf16 ? ((n_leaves + 1u) * 2u + 3u) & ~3u : 0u;
   uint32_t jump_bytes = J > 0 ? (2u << (3 * J)) : 0u;
-  if ((size_t)used + jump_bytes + (size_t)n_words * 4u > (size_t)lds_bytes) {  // keep the node words in LDS first
+  if ((size_t)used + jump_bytes + branch_bytes + leaf_bytes > (size_t)lds_bytes) {  // node words in LDS first
     J = 0;
     jump_bytes = 0;
   }
   uint16_t* ljump = reinterpret_cast<uint16_t*>(smem + used);
   used += jump_bytes;
   uint32_t* lwords = reinterpret_cast<uint32_t*>(smem + used);
-  const bool words_in_lds = (size_t)used + (size_t)n_words * 4u <= (size_t)lds_bytes;
+  uint16_t* lleaf = reinterpret_cast<uint16_t*>(smem + used + branch_bytes);
+  const bool words_in_lds = (size_t)used + branch_bytes + leaf_bytes <= (size_t)lds_bytes;
 
   for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
     lut_h[i] = (float)i / 180.0f;
@@ -294,12 +325,16 @@ __global__ __launch_bounds__(PFT_LIK_THREADS) void k_likelihood(PftParams prm, P
     uint32_t* dst = reinterpret_cast<uint32_t*>(ljump);
     for (uint32_t i = threadIdx.x; i < jump_bytes / 4u; i += blockDim.x) dst[i] = src[i];
   }
-  if (words_in_lds)
-    for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) lwords[i] = d.words[i];
+  if (words_in_lds) {
+    const uint32_t nb = leaf16 ? leaf_start : n_words;
+    for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) lwords[i] = d.words[i];
+    if (leaf16)
+      for (uint32_t i = threadIdx.x; i <= n_leaves; i += blockDim.x) lleaf[i] = (uint16_t)d.words[leaf_start + i];
+  }
   __syncthreads();
 
   LikCtx cx;
-  cx.words = words_in_lds ? lwords : d.words;
+  cx.words = nullptr;
   cx.tab = tab;
   cx.per_axis = per_axis;
   cx.lut_h = lut_h;
@@ -313,20 +348,48 @@ __global__ __launch_bounds__(PFT_LIK_THREADS) void k_likelihood(PftParams prm, P
   cx.ominz = hdr->ominf[2];
   cx.inv_res = hdr->inv_res;
   cx.ncell = (float)(1u << (D > 0 ? D : 0));
-  if (fast)
-    likelihood_items<true, true, DEBUG_NN>(prm, d, cx, n_particles, D, n_crop, omin);
-  else if (use_tab)
-    likelihood_items<true, false, DEBUG_NN>(prm, d, cx, n_particles, D, n_crop, omin);
-  else
-    likelihood_items<false, false, DEBUG_NN>(prm, d, cx, n_particles, D, n_crop, omin);
+  cx.leaf0 = hdr->leaf_start;
+  cx.leaf16 = lleaf;
+  if (words_in_lds && leaf16) {  // node words addressed as LDS (ds_read), not through a generic pointer
+    const uint32_t* W = lwords;
+    if (fast)
+      likelihood_items<true, true, DEBUG_NN, true>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+    else if (use_tab)
+      likelihood_items<true, false, DEBUG_NN, true>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+    else
+      likelihood_items<false, false, DEBUG_NN, true>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+  } else if (words_in_lds) {
+    const uint32_t* W = lwords;
+    if (fast)
+      likelihood_items<true, true, DEBUG_NN, false>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+    else if (use_tab)
+      likelihood_items<true, false, DEBUG_NN, false>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+    else
+      likelihood_items<false, false, DEBUG_NN, false>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+  } else {
+    const uint32_t* __restrict__ W = d.words;
+    if (fast)
+      likelihood_items<true, true, DEBUG_NN, false>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+    else if (use_tab)
+      likelihood_items<true, false, DEBUG_NN, false>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+    else
+      likelihood_items<false, false, DEBUG_NN, false>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+  }
 }
 
 static int g_allow_fast = -1;
 
+// timing experiments only (tools/lik_microbench.py): bit0 generic levels, bit1 leaf scan, bit2 coherence
+extern "C" void pft_debug_set_ablate(int mask) {
+  if (g_allow_fast < 0) g_allow_fast = 1;
+  g_allow_fast = (g_allow_fast & 0xff) | (mask << 8);
+}
+
 void pftk_likelihood(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, bool debug_nn,
                      int num_cus) {
   static bool attr_set = false;
-  uint32_t lds = (uint32_t)pftk_max_lds_bytes();
+  // half of the CU's LDS per workgroup: two 1024-thread workgroups (32 waves, 8 per SIMD) are resident per CU
+  uint32_t lds = ((uint32_t)pftk_max_lds_bytes() / (uint32_t)PFT_LIK_WGS_PER_CU) & ~255u;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_likelihood<false>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -337,9 +400,11 @@ void pftk_likelihood(hipStream_t s, const PftParams& p, const PftDev& d, uint32_
   if (g_allow_fast < 0) {  // PFT_GENERIC_DESCENT=1: all-generic descent (A/B and parity cross-check)
     const char* e = getenv("PFT_GENERIC_DESCENT");
     g_allow_fast = (e && e[0] == '1') ? 0 : 1;
+    const char* a = getenv("PFT_ABLATE");  // timing experiments only: bit0 generic levels, bit1 leaf scan, bit2 coherence
+    if (a) g_allow_fast |= atoi(a) << 8;
   }
   uint32_t items = n_particles * p.nchunk;
-  uint32_t grid = (uint32_t)num_cus;
+  uint32_t grid = (uint32_t)PFT_LIK_WGS_PER_CU * (uint32_t)num_cus;
   uint32_t need = (items + (PFT_LIK_THREADS / 64) - 1) / (PFT_LIK_THREADS / 64);
   if (need == 0) need = 1;
   if (grid > need) grid = need;

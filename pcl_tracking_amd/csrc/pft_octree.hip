@@ -21,7 +21,7 @@ struct BuildSh {
   int depth, ngrow;
   uint32_t cur, err, carry;
   int jump;
-  uint32_t u32s[20];
+  uint32_t u32s[40];
   uint32_t gidx[PFT_MAX_GROW], gshift[PFT_MAX_GROW], gold[PFT_MAX_GROW];
   double gmin[PFT_MAX_GROW + 1][3];
   uint32_t lvl[PFT_MAX_DEPTH + 3];
@@ -87,72 +87,56 @@ __device__ __forceinline__ bool box_violates(float x, float y, float z, const do
   return (x < mn[0]) || (y < mn[1]) || (z < mn[2]) || (x >= mx[0]) || (y >= mx[1]) || (z >= mx[2]);
 }
 
-// K points per thread (i = tid + j*1024); COORDS: keep xyz in registers across the rounds
-template <int K, bool COORDS>
+// Replay of the growth sequence.  The box after the first few dozen points usually contains everything,
+// so: (a) wave 0 alone handles the growth events among the first 64 points (one ballot per event, no
+// workgroup barrier); (b) the workgroup then looks for later violators with a per-thread AABB quick reject;
+// each remaining event costs one min-index reduction.
 __device__ __forceinline__ void box_replay(BuildSh& S, const float4* __restrict__ pts, uint32_t n, double res) {
-  const uint32_t tid = threadIdx.x;
-  float px[COORDS ? K : 1], py[COORDS ? K : 1], pz[COORDS ? K : 1];
-  float lmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, lmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-#pragma unroll
-  for (int j = 0; j < K; j++) {
-    uint32_t i = tid + j * PFT_BUILD_THREADS;
-    if (i < n) {
-      float4 p = pts[i];
-      if (COORDS) {
-        px[j] = p.x; py[j] = p.y; pz[j] = p.z;
-      }
-      lmn[0] = fminf(lmn[0], p.x); lmx[0] = fmaxf(lmx[0], p.x);
-      lmn[1] = fminf(lmn[1], p.y); lmx[1] = fmaxf(lmx[1], p.y);
-      lmn[2] = fminf(lmn[2], p.z); lmx[2] = fmaxf(lmx[2], p.z);
-    }
-    UNROLL_FENCE(j, 4);
-  }
-  for (;;) {
-    const uint32_t cur = S.cur;
-    const double mn[3] = {S.mn[0], S.mn[1], S.mn[2]};
-    const double mx[3] = {S.mx[0], S.mx[1], S.mx[2]};
-    uint32_t first = 0xffffffffu;
-    // thread-local box first: once it fits, none of this thread's points can violate
-    if (box_violates(lmn[0], lmn[1], lmn[2], mn, mx) || box_violates(lmx[0], lmx[1], lmx[2], mn, mx)) {
-#pragma unroll
-      for (int j = K - 1; j >= 0; j--) {
-        uint32_t i = tid + j * PFT_BUILD_THREADS;
-        if (i < n && i >= cur) {
-          float x, y, z;
-          if (COORDS) {
-            x = px[j]; y = py[j]; z = pz[j];
-          } else {
-            float4 p = pts[i];
-            x = p.x; y = p.y; z = p.z;
-          }
-          if (box_violates(x, y, z, mn, mx)) first = i;
-        }
-      }
-    }
-    first = block_reduce<uint32_t>(first, S.u32s, OpMinU(), 0xffffffffu);
-    if (first == 0xffffffffu) break;
-    if (tid == 0) {
-      box_grow(S, pts[first], first, res);
-      S.cur = first + 1;
-    }
-    __syncthreads();
-    if (S.err) break;
-  }
-}
-
-// generic replay: any n
-__device__ __forceinline__ void box_replay_generic(BuildSh& S, const float4* __restrict__ pts, uint32_t n, double res) {
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t head = n < 64u ? n : 64u;
+  if (tid < WAVE) {
+    const float4 p = tid < n ? pts[tid] : pts[0];
+    uint32_t cur = 1;
+    for (;;) {
+      const double mn[3] = {S.mn[0], S.mn[1], S.mn[2]};
+      const double mx[3] = {S.mx[0], S.mx[1], S.mx[2]};
+      const bool viol = tid >= cur && tid < head && box_violates(p.x, p.y, p.z, mn, mx);
+      const unsigned long long bal = __ballot(viol);
+      if (!bal) break;
+      const int f = __ffsll((long long)bal) - 1;
+      const float4 pf = make_float4(__shfl(p.x, f), __shfl(p.y, f), __shfl(p.z, f), 0.0f);
+      if (tid == 0) box_grow(S, pf, (uint32_t)f, res);
+      cur = (uint32_t)f + 1u;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // lane 0's LDS writes -> the wave's next reads
+      __builtin_amdgcn_wave_barrier();
+      if (S.err) break;
+    }
+    if (tid == 0) S.cur = head;
+  }
+  __syncthreads();
+  if (S.err || n <= 64u) return;
+  // (b) points 64.. : thread-local AABB of the thread's strided points
+  float lmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, lmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (uint32_t i = 64u + tid; i < n; i += nt) {
+    const float4 p = pts[i];
+    lmn[0] = fminf(lmn[0], p.x); lmx[0] = fmaxf(lmx[0], p.x);
+    lmn[1] = fminf(lmn[1], p.y); lmx[1] = fmaxf(lmx[1], p.y);
+    lmn[2] = fminf(lmn[2], p.z); lmx[2] = fmaxf(lmx[2], p.z);
+  }
   for (;;) {
     const uint32_t cur = S.cur;
     const double mn[3] = {S.mn[0], S.mn[1], S.mn[2]};
     const double mx[3] = {S.mx[0], S.mx[1], S.mx[2]};
     uint32_t first = 0xffffffffu;
-    for (uint32_t i = cur + tid; i < n; i += nt) {
-      float4 p = pts[i];
-      if (box_violates(p.x, p.y, p.z, mn, mx)) {
-        first = i;
-        break;
+    if (box_violates(lmn[0], lmn[1], lmn[2], mn, mx) || box_violates(lmx[0], lmx[1], lmx[2], mn, mx)) {
+      uint32_t i0 = 64u + tid;
+      if (i0 < cur) i0 += ((cur - i0 + nt - 1) / nt) * nt;
+      for (uint32_t i = i0; i < n; i += nt) {
+        const float4 p = pts[i];
+        if (box_violates(p.x, p.y, p.z, mn, mx)) {
+          first = i;
+          break;
+        }
       }
     }
     first = block_reduce<uint32_t>(first, S.u32s, OpMinU(), 0xffffffffu);
@@ -179,7 +163,7 @@ struct RegStore {
     for (int j = 0; j < K; j++) {
       uint32_t i = threadIdx.x + j * PFT_BUILD_THREADS;
       if (i < n) f(i, key[j], node[j]);
-      UNROLL_FENCE(j, 4);
+      UNROLL_FENCE(j, 2);
     }
   }
 };
@@ -192,6 +176,7 @@ struct GlobStore {
   __device__ GlobStore(const PftDev& d) : key(d.pt_key64), node(d.pt_node) {}
   template <class F>
   __device__ __forceinline__ void each(uint32_t n, F&& f) {
+#pragma unroll 4
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) f(i, key[i], node[i]);
   }
 };
@@ -202,15 +187,17 @@ __device__ __forceinline__ uint32_t key_child(KT k, int bit) {
          (uint32_t)((k >> bit) & 1);
 }
 
-template <class Store>
-__device__ __forceinline__ void build_tree(const PftParams& prm, const PftDev& d, BuildSh& S, uint32_t n, uint32_t* lds_words,
+// LDSW: node words and the leaf scratch list live in LDS (typed pointers: ds_* instructions); otherwise in HBM.
+// Returns false if the node words outgrow LDS (the caller then rebuilds in HBM mode).
+template <class Store, bool LDSW, bool TMPLDS>
+__device__ __forceinline__ bool build_tree(const PftParams& prm, const PftDev& d, BuildSh& S, uint32_t n, uint32_t* lds_words,
                            uint32_t lds_words_cap, uint32_t* lds_tmp, uint32_t* out_leaf_start,
                            uint32_t* out_n_leaves) {
   typedef typename Store::key_t key_t;
   constexpr int B = Store::B;
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   const float4* pts = d.crop_pts;
-  const double res = prm.res;
+  const double res = prm.res, inv_res = 1.0 / prm.res;
   const int D = S.depth, ngrow = S.ngrow;
   Store st(d);
 
@@ -219,9 +206,18 @@ __device__ __forceinline__ void build_tree(const PftParams& prm, const PftDev& d
     float4 p = pts[i];
     int e = 0;
     while (e < ngrow && S.gidx[e] <= i) e++;
-    uint32_t kx = (uint32_t)(((double)p.x - S.gmin[e][0]) / res);
-    uint32_t ky = (uint32_t)(((double)p.y - S.gmin[e][1]) / res);
-    uint32_t kz = (uint32_t)(((double)p.z - S.gmin[e][2]) / res);
+    // (unsigned)((p - min) / res) in double, as genOctreeKeyforPoint: the product with 1/res agrees with
+    // the correctly rounded quotient to ~1e-13, so it is used unless it lands within 1e-6 of an integer
+    const double tq[3] = {(double)p.x - S.gmin[e][0], (double)p.y - S.gmin[e][1], (double)p.z - S.gmin[e][2]};
+    uint32_t kk[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      double q0 = tq[a] * inv_res;
+      const double fr = q0 - floor(q0);
+      if (fr < 1.0e-6 || fr > 1.0 - 1.0e-6) q0 = tq[a] / res;
+      kk[a] = (uint32_t)q0;
+    }
+    uint32_t kx = kk[0], ky = kk[1], kz = kk[2];
     for (int s = e; s < ngrow; s++) {
       uint32_t sh = S.gshift[s], od = S.gold[s];
       if (sh & 1u) kx += 1u << od;
@@ -236,7 +232,7 @@ __device__ __forceinline__ void build_tree(const PftParams& prm, const PftDev& d
   });
 
   STAMP(2);
-  uint32_t* W = (lds_words && lds_words_cap >= 16) ? lds_words : d.words;
+  uint32_t* W = LDSW ? lds_words : d.words;
   // direct-index table of the level-J nodes for the likelihood kernel's fast descent
   const int J = (D >= 4 && D <= PFT_TABLE_MAX_DEPTH) ? (D - 1 < PFT_JUMP_MAX_LEVEL ? D - 1 : PFT_JUMP_MAX_LEVEL) : 0;
   if (J > 0) {
@@ -252,8 +248,10 @@ __device__ __forceinline__ void build_tree(const PftParams& prm, const PftDev& d
   __syncthreads();
 
   // ---- levels ----
+  unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, t0_, t1_;
   for (int l = 0; l < D; l++) {
     const int bit = D - 1 - l;
+    t0_ = wall_clock64();
     const uint32_t lvl_first = S.lvl[l];
     st.each(n, [&](uint32_t, key_t& key, uint32_t& node) {
       if (l > 0) {  // move to the level-l node chosen by the previous level's bits
@@ -267,19 +265,40 @@ __device__ __forceinline__ void build_tree(const PftParams& prm, const PftDev& d
                        cz = (uint32_t)(key >> sh) & mk;
         d.jump[cx | (cy << J) | (cz << (2 * J))] = (uint16_t)(node - lvl_first + 1u);
       }
-      atomicOr(&W[node], 1u << key_child<key_t, B>(key, bit));
+      // near the root thousands of points share a word: test first, so only the first arrivals pay for the
+      // (same-address, serialised) LDS atomic
+      const uint32_t cb = 1u << key_child<key_t, B>(key, bit);
+      if (!(W[node] & cb)) atomicOr(&W[node], cb);
     });
     __syncthreads();
+    t1_ = wall_clock64(); tA += t1_ - t0_; t0_ = t1_;
     // child_base: each thread owns a contiguous run of this level's nodes, one workgroup scan per level
+    // (two barriers: the scan scratch alternates between levels); the next level's words are zeroed in the
+    // same phase as the bases are written
     const uint32_t ls = S.lvl[l], le = S.lvl[l + 1], nl = le - ls;
     const uint32_t per = (nl + nt - 1) / nt;
     const uint32_t a0 = ls + min(nl, tid * per), a1 = ls + min(nl, (tid + 1) * per);
     uint32_t cnt = 0;
     for (uint32_t nd = a0; nd < a1; nd++) cnt += __popc(W[nd] & 0xffu);
-    uint32_t total;
-    uint32_t base = le + block_excl_scan<uint32_t>(cnt, S.u32s, &total);
-    const uint32_t nend = le + total;
-    if (nend + 2 > d.max_words || nend >= (1u << 24)) {
+    t1_ = wall_clock64(); tB += t1_ - t0_; t0_ = t1_;
+    uint32_t* scr = S.u32s + (l & 1) * 20;
+    uint32_t inc = wave_incl_scan(cnt);
+    if (lane_id() == WAVE - 1) scr[wave_id()] = inc;
+    __syncthreads();
+    if (wave_id() == 0) {
+      const int nw = (int)(nt >> 6);
+      uint32_t t = lane_id() < nw ? scr[lane_id()] : 0u;
+      uint32_t ti = wave_incl_scan(t);
+      if (lane_id() < nw) scr[lane_id()] = ti - t;
+      if (lane_id() == nw - 1) scr[17] = ti;
+    }
+    __syncthreads();
+    t1_ = wall_clock64(); tC += t1_ - t0_; t0_ = t1_;
+    uint32_t base = le + scr[wave_id()] + inc - cnt;
+    const uint32_t nend = le + scr[17];
+    const bool overflow = nend + 2 > d.max_words || nend >= (1u << 24);
+    if (LDSW && !overflow && nend + 2 > lds_words_cap) return false;  // uniform: node words outgrew LDS
+    if (overflow) {
       if (tid == 0) S.err |= 1u;
     } else {
       for (uint32_t nd = a0; nd < a1; nd++) {
@@ -287,22 +306,19 @@ __device__ __forceinline__ void build_tree(const PftParams& prm, const PftDev& d
         W[nd] = wv | (base << 8);
         base += __popc(wv & 0xffu);
       }
+      for (uint32_t j = le + tid; j < nend; j += nt) W[j] = 0;
     }
     if (tid == 0) S.lvl[l + 2] = nend;
     __syncthreads();
+    t1_ = wall_clock64(); tD += t1_ - t0_;
     if (S.err) break;
-    if (W != d.words && nend + 2 > lds_words_cap) {  // node words outgrew LDS: continue in HBM
-      for (uint32_t j = tid; j < le; j += nt) d.words[j] = W[j];
-      W = d.words;
-    }
-    for (uint32_t j = le + tid; j < nend; j += nt) W[j] = 0;
-    __syncthreads();
   }
+  if (tid == 0) { d.hdr->ticks[9] = tA; d.hdr->ticks[10] = tB; d.hdr->ticks[11] = tC; d.hdr->ticks[12] = tD; }
   __syncthreads();
   if (S.err || D <= 0) {
     *out_leaf_start = 0;
     *out_n_leaves = 0;
-    return;
+    return true;
   }
 
   // ---- leaves ----
@@ -332,7 +348,7 @@ __device__ __forceinline__ void build_tree(const PftParams& prm, const PftDev& d
   if (tid == 0) W[leaf_start + n_leaves] = n;  // sentinel: count(leaf j) = start[j+1] - start[j]
   __syncthreads();
   STAMP(4);
-  uint32_t* TMP = lds_tmp ? lds_tmp : d.pt_tmp;
+  uint32_t* TMP = TMPLDS ? lds_tmp : d.pt_tmp;
   st.each(n, [&](uint32_t i, key_t& key, uint32_t& node) { TMP[W[node] + (uint32_t)key] = i; });
   __syncthreads();
   STAMP(5);
@@ -345,24 +361,34 @@ __device__ __forceinline__ void build_tree(const PftParams& prm, const PftDev& d
   });
   STAMP(6);
   const uint32_t n_words = leaf_start + n_leaves + 1;
-  if (W != d.words)
+  if (LDSW)
     for (uint32_t j = tid; j < n_words; j += nt) d.words[j] = W[j];
   *out_leaf_start = leaf_start;
   *out_n_leaves = n_leaves;
+  return true;
+}
+
+template <class Store>
+__device__ __forceinline__ void build_tree_any(const PftParams& prm, const PftDev& d, BuildSh& S, uint32_t n,
+                                               uint32_t* lds_words, uint32_t cap, uint32_t* lds_tmp, uint32_t* ls,
+                                               uint32_t* nl) {
+  bool done = false;
+  if (cap >= 64) {
+    if (lds_tmp) done = build_tree<Store, true, true>(prm, d, S, n, lds_words, cap, lds_tmp, ls, nl);
+    else done = build_tree<Store, true, false>(prm, d, S, n, lds_words, cap, lds_tmp, ls, nl);
+  }
+  __syncthreads();
+  if (!done) build_tree<Store, false, false>(prm, d, S, n, lds_words, cap, lds_tmp, ls, nl);
 }
 
 template <int K>
 __device__ __forceinline__ void build_regs(const PftParams& prm, const PftDev& d, BuildSh& S, uint32_t n, uint32_t* lds_words,
                            uint32_t cap, uint32_t* lds_tmp, uint32_t* ls, uint32_t* nl, int* path) {
-  box_replay<K, (K <= 16)>(S, d.crop_pts, n, prm.res);
-  __syncthreads();
-  STAMP(1);
-  if (S.err) return;
   if (S.depth <= RegStore<K>::B) {
     *path = 1;
-    build_tree<RegStore<K>>(prm, d, S, n, lds_words, cap, lds_tmp, ls, nl);
+    build_tree_any<RegStore<K>>(prm, d, S, n, lds_words, cap, lds_tmp, ls, nl);
   } else {
-    build_tree<GlobStore>(prm, d, S, n, lds_words, cap, lds_tmp, ls, nl);
+    build_tree_any<GlobStore>(prm, d, S, n, lds_words, cap, lds_tmp, ls, nl);
   }
 }
 
@@ -383,12 +409,12 @@ __global__ __launch_bounds__(PFT_BUILD_THREADS) void k_octree_build(PftParams pr
   }
   __syncthreads();
 
-  // LDS carve: [tmp list: n words, if it leaves >= 2/3 for the nodes][node words]
+  // LDS carve: [leaf scratch list: n words, if the node words (about 1.5 n) still fit beside it][node words]
   uint32_t* lds_u = reinterpret_cast<uint32_t*>(smem);
   const uint32_t lds_words_total = lds_bytes / 4u;
   uint32_t* lds_tmp = nullptr;
   uint32_t tmp_words = 0;
-  if ((size_t)n * 3u <= lds_words_total) {
+  if ((size_t)n * 5u / 2u + 64u <= lds_words_total) {
     lds_tmp = lds_u;
     tmp_words = (n + 3u) & ~3u;
   }
@@ -398,15 +424,14 @@ __global__ __launch_bounds__(PFT_BUILD_THREADS) void k_octree_build(PftParams pr
   uint32_t leaf_start = 0, n_leaves = 0;
   int path = 0;
   if (n > 0) {
+    box_replay(S, d.crop_pts, n, prm.res);
+    __syncthreads();
+    STAMP(1);
+  }
+  if (n > 0 && !S.err) {
     if (n <= 4u * PFT_BUILD_THREADS) build_regs<4>(prm, d, S, n, lds_words, cap, lds_tmp, &leaf_start, &n_leaves, &path);
     else if (n <= 8u * PFT_BUILD_THREADS) build_regs<8>(prm, d, S, n, lds_words, cap, lds_tmp, &leaf_start, &n_leaves, &path);
-    else if (n <= 16u * PFT_BUILD_THREADS) build_regs<16>(prm, d, S, n, lds_words, cap, lds_tmp, &leaf_start, &n_leaves, &path);
-    else if (n <= 32u * PFT_BUILD_THREADS) build_regs<32>(prm, d, S, n, lds_words, cap, lds_tmp, &leaf_start, &n_leaves, &path);
-    else {
-      box_replay_generic(S, d.crop_pts, n, prm.res);
-      __syncthreads();
-      if (!S.err) build_tree<GlobStore>(prm, d, S, n, lds_words, cap, lds_tmp, &leaf_start, &n_leaves);
-    }
+    else build_tree_any<GlobStore>(prm, d, S, n, lds_words, cap, lds_tmp, &leaf_start, &n_leaves);
   }
   __syncthreads();
   STAMP(7);

@@ -1,0 +1,6 @@
+#!/bin/bash
+# stage shares of k_likelihood by ablation (timing only; results are wrong by construction)
+for a in 0 1 2 4 3 7; do
+  echo -n "PFT_ABLATE=$a  "
+  PFT_ABLATE=$a python bench.py --steps 30 --warmup 10 --no-cpu-baseline | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('lik us', round(d['roofline']['avg_launch_us'],1), 'frame ms', round(d['ms_per_step'],3))"
+done

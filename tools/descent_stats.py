@@ -28,6 +28,7 @@ print("crop", len(st["crop_idx"]), "depth", st["octree_depth"], "leaves", st["n_
       "kbar", st["scan_points"] / max(1, st["scan_queries"]))
 print("queries by #generic levels:", (d[:11] / q).round(4), "mean", (d[:11] * np.arange(11)).sum() / q)
 print("jump used:", d[11] / q)
+print("queries by #hard steps (ideal child missing) 0,1,2,3,4+:", (d[27:32] / q).round(4), "mean", (d[27:32] * np.arange(5)).sum() / q)
 wi = d[12]
 print("per wave-iteration: max generic %.2f  max fast %.2f  max leaf %.2f" % (d[13] / wi, d[14] / wi, d[15] / wi))
 print("wave iterations by max generic:", (d[16:27] / wi).round(4))

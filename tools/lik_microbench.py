@@ -1,0 +1,35 @@
+"""Stage shares of k_likelihood on a FIXED particle set (steady state of BASELINE configs[1]): the tracker
+runs normally, then pft_eval_weights is timed on its particles with stages ablated (timing only)."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pcl_tracking_amd import scene, tracker  # noqa: E402
+
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+reps = 10
+model = scene.make_model(2048)
+cloud = scene.make_scene(50000)
+t = tracker.make_reference_tracker(particle_num=P, seed=1)
+t.setReferenceCloud(model)
+t.setTrans(scene.initial_trans())
+t.setInputCloud(cloud)
+for i in range(frames):
+    t.compute()
+p = t.getParticles()
+t.profileEnable(True)
+for mask, name in ((0, "full"), (1, "no generic levels"), (2, "no leaf scan"), (4, "no coherence"), (6, "descent only"),
+                   (7, "transform+key+fast only")):
+    t._L.pft_debug_set_ablate(mask)
+    t.evalWeights(p)
+    t.profileReset()
+    for r in range(reps):
+        t.evalWeights(p)
+    pr = t.profileGet()
+    print("%-26s likelihood %.1f us   octree %.1f us   aabb %.1f us" % (
+        name, pr["likelihood"][0] / pr["likelihood"][1] * 1e3, pr["octree"][0] / pr["octree"][1] * 1e3,
+        pr["aabb"][0] / pr["aabb"][1] * 1e3))
+t._L.pft_debug_set_ablate(0)

@@ -17,7 +17,7 @@ t = tracker.make_reference_tracker(particle_num=P, seed=1)
 t.setReferenceCloud(model)
 t.setTrans(scene.initial_trans())
 t.setInputCloud(cloud)
-for i in range(10):
+for i in range(int(sys.argv[3]) if len(sys.argv) > 3 else 10):
     t.compute()
 t.synchronize()
 tk = np.zeros(32, np.uint64)
@@ -25,6 +25,7 @@ t._check(t._L.pft_debug_get_ticks(t._h, tk.ctypes.data_as(C.c_void_p)))
 o = tk[:9].astype(np.int64)
 names = ["init", "replay", "keys", "levels", "leaf-count+scan", "leaf-scatter", "leaf-rank+gather", "flush", "tables"]
 print("octree phases (us):", dict(zip(names[1:], ((o[1:] - o[:-1]) / 100.0).round(2))), "total", (o[8] - o[0]) / 100.0)
+print("  levels split (us): point pass %.2f  count %.2f  scan %.2f  write+zero %.2f" % tuple(tk[9:13].astype(np.float64) / 100.0))
 p = tk[16:22].astype(np.int64)
 names = ["load", "normalize", "mean", "alias-pass1", "alias-scan+pass2"]
 print("population phases (us):", dict(zip(names, ((p[1:] - p[:-1]) / 100.0).round(2))), "total", (p[5] - p[0]) / 100.0)
