@@ -150,6 +150,8 @@ int pft_debug_get_descent_stats(pft_tracker* t, uint64_t* dbg32);
 /* timing experiments only: skip stages of the likelihood kernel (bit0 generic levels, bit1 leaf scan,
  * bit2 coherence); results are wrong by construction while a mask is set */
 void pft_debug_set_ablate(int mask);
+/* diagnostic: resident likelihood workgroups per CU according to the HIP occupancy API */
+int pft_debug_likelihood_occupancy(void);
 int pft_debug_normalize(pft_tracker* t, float* w_inout, size_t n, double* fit_ratio);
 int pft_debug_alias(pft_tracker* t, const float* w, size_t n, int32_t* a, double* q);
 int pft_debug_weighted_mean(pft_tracker* t, const pft_particle* p, size_t n, pft_particle* out);

@@ -70,6 +70,7 @@ SYMBOLS = [
     ("pft_debug_get_ticks", C.c_int, [_vp, _vp]),
     ("pft_debug_get_descent_stats", C.c_int, [_vp, _vp]),
     ("pft_debug_set_ablate", None, [C.c_int]),
+    ("pft_debug_likelihood_occupancy", C.c_int, []),
     ("pft_debug_normalize", C.c_int, [_vp, _vp, _sz, _P(_f64)]),
     ("pft_debug_alias", C.c_int, [_vp, _vp, _sz, _vp, _vp]),
     ("pft_debug_weighted_mean", C.c_int, [_vp, _vp, _sz, _vp]),

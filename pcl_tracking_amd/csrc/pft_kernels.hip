@@ -125,6 +125,7 @@ __global__ __launch_bounds__(1024) void k_aabb(const float4* __restrict__ ref, u
   for (uint32_t pi = gw; pi < n_particles; pi += tw) {
     float T[12];
     load_matrix(mats, pi, T);
+#pragma unroll 4
     for (uint32_t j = lane; j < M; j += WAVE) {
       float4 r = src[j];
       float x, y, z;

@@ -379,6 +379,15 @@ __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * 
 
 static int g_allow_fast = -1;
 
+// diagnostic: resident workgroups per CU the runtime reports for the production likelihood kernel
+extern "C" int pft_debug_likelihood_occupancy(void) {
+  int nb = -1;
+  uint32_t lds = ((uint32_t)pftk_max_lds_bytes() / (uint32_t)PFT_LIK_WGS_PER_CU) & ~255u;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&k_likelihood<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_likelihood<false>), PFT_LIK_THREADS, lds) != hipSuccess) return -1;
+  return nb;
+}
+
 // timing experiments only (tools/lik_microbench.py): bit0 generic levels, bit1 leaf scan, bit2 coherence
 extern "C" void pft_debug_set_ablate(int mask) {
   if (g_allow_fast < 0) g_allow_fast = 1;
