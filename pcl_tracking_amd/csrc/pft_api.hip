@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
 #include <cmath>
 #include <string>
@@ -57,6 +59,9 @@ struct pft_tracker {
   float4* d_leaf_pts = nullptr;
   uint32_t *d_leaf_order = nullptr, *d_pt_node = nullptr, *d_pt_key = nullptr, *d_pt_tmp = nullptr;
   unsigned long long* d_pt_key64 = nullptr;
+  SortBufs sort = {};
+  uint32_t* h_stat = nullptr;   // pinned, device-visible
+  int force_builder = 0;        // PFT_FORCE_BUILDER: 1 single workgroup, 2 sorted
   double* d_partial = nullptr;
   int32_t* d_alias_list = nullptr;
   double* d_alias_pref = nullptr;
@@ -257,6 +262,7 @@ static void sync_dev(pft_tracker* t) {
   d.pt_key = t->d_pt_key;
   d.pt_tmp = t->d_pt_tmp;
   d.pt_key64 = t->d_pt_key64;
+  d.host_stat = t->h_stat;
   d.partial = t->d_partial;
   d.alias_list = t->d_alias_list;
   d.alias_pref = t->d_alias_pref;
@@ -276,6 +282,8 @@ static int ensure_input_capacity(pft_tracker* t, uint32_t n) {
   dfree(t->d_in_raw); dfree(t->d_in_pts); dfree(t->d_crop_counts); dfree(t->d_crop_pts); dfree(t->d_crop_idx);
   dfree(t->d_words); dfree(t->d_leaf_pts); dfree(t->d_leaf_order); dfree(t->d_pt_node); dfree(t->d_pt_key);
   dfree(t->d_pt_tmp); dfree(t->d_pt_key64);
+  dfree(t->sort.keys[0]); dfree(t->sort.keys[1]); dfree(t->sort.vals[0]); dfree(t->sort.vals[1]);
+  dfree(t->sort.hist); dfree(t->sort.tile_cnt); dfree(t->sort.tile_box);
   uint32_t cap = n;
   t->max_words = cap * 8u + 64u;
   HIPCHK(t, dalloc(&t->d_in_raw, cap));
@@ -290,6 +298,14 @@ static int ensure_input_capacity(pft_tracker* t, uint32_t n) {
   HIPCHK(t, dalloc(&t->d_pt_key, (size_t)cap * 3));
   HIPCHK(t, dalloc(&t->d_pt_tmp, cap));
   HIPCHK(t, dalloc(&t->d_pt_key64, cap));
+  t->sort.ntiles = (cap + 1023u) / 1024u;
+  HIPCHK(t, dalloc(&t->sort.keys[0], cap));
+  HIPCHK(t, dalloc(&t->sort.keys[1], cap));
+  HIPCHK(t, dalloc(&t->sort.vals[0], cap));
+  HIPCHK(t, dalloc(&t->sort.vals[1], cap));
+  HIPCHK(t, dalloc(&t->sort.hist, (size_t)256 * t->sort.ntiles + 256));
+  HIPCHK(t, dalloc(&t->sort.tile_cnt, (size_t)t->sort.ntiles * (PFT_MAX_DEPTH + 2)));
+  HIPCHK(t, dalloc(&t->sort.tile_box, (size_t)t->sort.ntiles * 6));
   t->in_cap = cap;
   return PFT_OK;
 }
@@ -359,6 +375,12 @@ extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
   A(dalloc(&t->d_alias_list, 2 * Pt));
   A(dalloc(&t->d_alias_pref, 2 * Pt));
   A(dalloc(&t->d_alias_pos, Pt));
+  A(hipHostMalloc(reinterpret_cast<void**>(&t->h_stat), 4 * sizeof(uint32_t), hipHostMallocMapped));
+  if (t->h_stat) t->h_stat[0] = t->h_stat[1] = 0;
+  {
+    const char* fb = getenv("PFT_FORCE_BUILDER");
+    t->force_builder = fb ? (!strcmp(fb, "single") ? 1 : (!strcmp(fb, "sorted") ? 2 : 0)) : 0;
+  }
   A(dalloc(&t->d_hdr, 1));
   A(dalloc(&t->d_dbg_hdr, 1));
   if (e == hipSuccess) e = hipMemsetAsync(t->d_hdr, 0, sizeof(PftHeader), t->stream);
@@ -396,7 +418,9 @@ extern "C" void pft_destroy(pft_tracker* t) {
   dfree(t->d_part[0]); dfree(t->d_part[1]); dfree(t->d_mats); dfree(t->d_bbox_part); dfree(t->d_bbox6);
   dfree(t->d_crop_counts); dfree(t->d_crop_pts); dfree(t->d_crop_idx); dfree(t->d_words); dfree(t->d_centers); dfree(t->d_jump); dfree(t->d_ref_perm);
   dfree(t->d_leaf_pts); dfree(t->d_leaf_order); dfree(t->d_pt_node); dfree(t->d_pt_key); dfree(t->d_pt_tmp);
-  dfree(t->d_pt_key64); dfree(t->d_partial); dfree(t->d_alias_list); dfree(t->d_alias_pos);
+  dfree(t->d_pt_key64); dfree(t->sort.keys[0]); dfree(t->sort.keys[1]); dfree(t->sort.vals[0]); dfree(t->sort.vals[1]);
+  dfree(t->sort.hist); dfree(t->sort.tile_cnt); dfree(t->sort.tile_box); if (t->h_stat) hipHostFree(t->h_stat);
+  dfree(t->d_partial); dfree(t->d_alias_list); dfree(t->d_alias_pos);
   dfree(t->d_alias_pref); dfree(t->d_hdr); dfree(t->d_nn_idx); dfree(t->d_nn_d2); dfree(t->d_dbg_part);
   dfree(t->d_dbg_hdr); dfree(t->d_dbg_f);
   if (t->own_stream && t->stream) hipStreamDestroy(t->stream);
@@ -555,7 +579,23 @@ static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32
   }
   {
     ProfScope ps(t, PFT_K_OCTREE);
-    pftk_octree(t->stream, t->prm, d);
+    // the single-workgroup builder is fastest for small crops, the sorted many-workgroup builder scales; both
+    // are correct for any size.  The choice uses the crop size / depth of the PREVIOUS iteration, read from
+    // pinned memory without synchronising.
+    const volatile uint32_t* hs = t->h_stat;
+    const uint32_t last_n = hs ? hs[0] : 0u, last_depth = hs ? hs[1] : 0u;
+    bool sorted = last_n > PFT_SORTED_BUILD_MIN;
+    if (t->force_builder == 1) sorted = false;
+    if (t->force_builder == 2) sorted = true;
+    if (sorted) {
+      // 8-bit passes for 3 bits per level; one level of head-room over the last depth (k_so_scan flags an error
+      // if the tree turned out deeper than the passes cover)
+      int npass = last_depth > 0u ? (int)((3u * (last_depth + 1u) + 7u) / 8u) : 8;
+      if (npass > 8) npass = 8;
+      pftk_octree_sorted(t->stream, t->prm, d, t->sort, d.N, npass);
+    }
+    else
+      pftk_octree(t->stream, t->prm, d);
   }
   {
     ProfScope ps(t, PFT_K_LIKELIHOOD);

@@ -32,6 +32,7 @@
 #define PFT_LIK_WGS_PER_CU 2    // resident likelihood workgroups per CU (each gets 1/N of the LDS)
 #endif
 #define PFT_POP_THREADS 1024
+#define PFT_SORTED_BUILD_MIN 20000  // cropped points (last iteration) above which the sorted builder is used
 #define PFT_MAX_PARTICLES (64 * PFT_POP_THREADS)  // population kernel: <= 64 particles per thread
 
 struct PftParams {  // immutable per handle, passed by value to kernels
@@ -65,6 +66,11 @@ struct PftHeader {  // lives in HBM; written by kernels, read by later kernels (
   float margin_cells;   // a query closer than this (in leaf cells) to a cell face takes the exact generic step
   float ominf[3];       // (float) omin
   float inv_res;        // (float)(1/res)
+  // growth history of the box replay (read by the key kernel of the sorted builder)
+  uint32_t grow_idx[PFT_MAX_GROW];
+  uint32_t grow_shift[PFT_MAX_GROW];      // bit a set: min of axis a lowered by the old side
+  uint32_t grow_old_depth[PFT_MAX_GROW];
+  double grow_min[PFT_MAX_GROW + 1][3];   // [e] = box minimum valid for points inserted in epoch e
   double fit_ratio;
   pft_particle rep;
   pft_particle motion;
@@ -104,6 +110,8 @@ struct PftDev {  // device pointers (host-side struct, passed by value)
   double* alias_pref;    // [0,P): running deficit, [P,2P): running excess
   uint32_t* alias_pos;   // [P]
   PftHeader* hdr;
+  uint32_t* host_stat;  // pinned host memory, device-visible: [0] last n_crop, [1] last octree depth (read by the
+                        // host WITHOUT synchronising, to pick the builder for the next iteration)
   int32_t* nn_idx;      // debug only
   float* nn_d2;
 };
@@ -122,6 +130,17 @@ void pftk_pose_to_matrix(hipStream_t s, const pft_particle* p, uint32_t n, float
 void pftk_aabb(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, bool finalize);
 void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d, bool bbox_from_partials);
 void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d);
+struct SortBufs {
+  unsigned long long* keys[2];
+  uint32_t* vals[2];
+  uint32_t* hist;      // [256][ntiles]
+  uint32_t* tile_cnt;  // [ntiles][PFT_MAX_DEPTH + 2]
+  float* tile_box;     // [ntiles][6] AABB of each 1024-point tile of the cropped cloud
+  uint32_t ntiles;
+};
+// many-workgroup builder for large cropped clouds (pft_octree_sorted.hip); npass = 4 (depth <= 10) or 8
+void pftk_octree_sorted(hipStream_t s, const PftParams& p, const PftDev& d, const SortBufs& sb, uint32_t n_pad,
+                        int npass);
 void pftk_likelihood(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, bool debug_nn,
                      int num_cus);
 void pftk_finalize_raw(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles,

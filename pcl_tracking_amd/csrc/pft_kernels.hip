@@ -227,7 +227,7 @@ __global__ __launch_bounds__(1024) void k_crop_scatter(const float4* __restrict_
                                                        const float* __restrict__ part, uint32_t nparts,
                                                        const uint32_t* __restrict__ counts, int argorder,
                                                        float4* __restrict__ out, int32_t* __restrict__ out_idx,
-                                                       PftHeader* __restrict__ hdr) {
+                                                       PftHeader* __restrict__ hdr, uint32_t* host_stat) {
   __shared__ uint32_t s_scan[20];
   __shared__ uint32_t s_base;
   __shared__ float s6[6];
@@ -260,6 +260,7 @@ __global__ __launch_bounds__(1024) void k_crop_scatter(const float4* __restrict_
   }
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
     hdr->n_crop = s_base + total;
+    if (host_stat) host_stat[0] = s_base + total;
     hdr->bbox[0] = -s6[0]; hdr->bbox[1] = s6[3];
     hdr->bbox[2] = -s6[1]; hdr->bbox[3] = s6[4];
     hdr->bbox[4] = -s6[2]; hdr->bbox[5] = s6[5];
@@ -356,12 +357,12 @@ void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d, bool from_par
     hipLaunchKernelGGL(k_crop_count<true>, dim3(nb), dim3(1024), 0, s, d.in_pts, d.N, d.bbox6, d.bbox_part,
                        d.bbox_grid, d.crop_counts);
     hipLaunchKernelGGL(k_crop_scatter<true>, dim3(nb), dim3(1024), 0, s, d.in_pts, d.N, d.bbox6, d.bbox_part,
-                       d.bbox_grid, d.crop_counts, p.hsv_argorder, d.crop_pts, d.crop_idx, d.hdr);
+                       d.bbox_grid, d.crop_counts, p.hsv_argorder, d.crop_pts, d.crop_idx, d.hdr, d.host_stat);
   } else {
     hipLaunchKernelGGL(k_crop_count<false>, dim3(nb), dim3(1024), 0, s, d.in_pts, d.N, d.bbox6, d.bbox_part,
                        d.bbox_grid, d.crop_counts);
     hipLaunchKernelGGL(k_crop_scatter<false>, dim3(nb), dim3(1024), 0, s, d.in_pts, d.N, d.bbox6, d.bbox_part,
-                       d.bbox_grid, d.crop_counts, p.hsv_argorder, d.crop_pts, d.crop_idx, d.hdr);
+                       d.bbox_grid, d.crop_counts, p.hsv_argorder, d.crop_pts, d.crop_idx, d.hdr, d.host_stat);
   }
 }
 void pftk_finalize_raw(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, float* raw_out) {

@@ -461,6 +461,7 @@ __global__ __launch_bounds__(PFT_BUILD_THREADS) void k_octree_build(PftParams pr
     hdr->use_table = use_table;
     hdr->n_grow = S.ngrow;
     hdr->build_path = path;
+    if (d.host_stat) d.host_stat[1] = (uint32_t)D;
     hdr->jump_level = (ok && use_table) ? S.jump : 0;
     {
       // safety margin of the fast descent (DESIGN.md "fast descent"): float rounding of the voxel centres

@@ -179,6 +179,31 @@ def test_eval_weights_ragged_sizes(gpu, orc, M, N, P):
         assert G["scan_points"] > 2 * G["scan_queries"]
 
 
+@pytest.mark.parametrize("M,N,P", [(65, 1025, 33), (2048, 50000, 128), (2048, 307200, 64)])
+def test_eval_weights_sorted_builder(gpu, orc, monkeypatch, M, N, P):
+    """the many-workgroup builder (Morton keys -> stable radix sort -> level construction), forced on at sizes
+    where the single-workgroup builder would normally run: same tree, same neighbours, bit for bit"""
+    monkeypatch.setenv("PFT_FORCE_BUILDER", "sorted")
+    model = scene.make_model(M, seed=M)
+    cloud = scene.make_scene(N, mode="organized") if N == 307200 else scene.make_scene(50000)[:N]
+    G, O = check_eval(gpu, orc, model, cloud, P, scene.model_gt_pose(), 300 + M)
+    monkeypatch.setenv("PFT_FORCE_BUILDER", "single")
+    G2, _ = check_eval(gpu, orc, model, cloud, P, scene.model_gt_pose(), 300 + M)
+    np.testing.assert_array_equal(G["nn_idx"], G2["nn_idx"])
+    assert G["n_words"] == G2["n_words"] and G["n_leaves"] == G2["n_leaves"]
+
+
+def test_compute_with_sorted_builder(gpu, orc, data, monkeypatch):
+    monkeypatch.setenv("PFT_FORCE_BUILDER", "sorted")
+    g, o = make_pair(gpu, orc, data["model"], data["scene"], 400, seed=3)
+    for f in range(3):
+        g.compute()
+        o.compute()
+        rg, ro = g.getResult(), o.get_result()
+        for k in ("x", "y", "z", "roll", "pitch", "yaw"):
+            assert abs(float(rg[k]) - float(ro[k])) < 1e-4
+
+
 def test_eval_weights_empty_crop(gpu, orc, data):
     far = (5.0, 5.0, 5.0, 0, 0, 0)
     check_eval(gpu, orc, data["model"], data["scene"], 64, far, 9, expect_empty=True)
