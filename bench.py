@@ -32,6 +32,7 @@ def parse():
     ap.add_argument("--model-points", type=int, default=M_MODEL)
     ap.add_argument("--cloud-points", type=int, default=N_CLOUD)
     ap.add_argument("--organized", action="store_true", help="N = w*h depth image, no downsample (config 3)")
+    ap.add_argument("--objects", type=int, default=1, help="independent trackers, one HIP stream each (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
     return ap.parse_args()
@@ -96,15 +97,21 @@ def main():
     if world == 1:
         from pcl_tracking_amd import tracker
 
-        t = tracker.make_reference_tracker(particle_num=P_total, seed=1, device_id=local_rank)
-        t.setReferenceCloud(model)
-        t.setTrans(trans)
+        # independent objects are independent handles, each on its own HIP stream (the reference tracks them in
+        # a sequential loop, auto_tracking.cpp:688-697)
+        ts = []
+        for k in range(ARGS.objects):
+            t = tracker.make_reference_tracker(particle_num=P_total, seed=1 + k, device_id=local_rank)
+            t.setReferenceCloud(model)
+            t.setTrans(trans)
+            ts.append(t)
 
         def step():
-            t.setInputCloudDevice(cloud_dev.data_ptr(), N, keepalive=cloud_dev)
-            t.compute()
+            for t in ts:
+                t.setInputCloudDevice(cloud_dev.data_ptr(), N, keepalive=cloud_dev)
+                t.compute()
 
-        trk = t
+        trk = ts[0]
     else:
         from pcl_tracking_amd.dist import HipPhases, ShardedFilter
 
@@ -165,7 +172,7 @@ def main():
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        pips = P_total * N / (dt / ARGS.steps)
+        pips = ARGS.objects * P_total * N / (dt / ARGS.steps)
         out = {
             "metric": "particles x input-points / sec per frame (tracked frames/sec @8192 particles per GPU)",
             "value": pips,
@@ -183,7 +190,7 @@ def main():
                 "workload": "BASELINE configs[1]: %d-pt model vs %d-pt %s cloud, %d particles/GPU, 2 iterations/frame, "
                             "single frame looped" % (M, N, "organized" if ARGS.organized else "voxel-downsampled", P_local),
                 "particles_total": P_total, "model_points": M, "cloud_points": N, "iterations_per_frame": 2,
-                "parallelism": "particles sharded x%d" % world,
+                "parallelism": "particles sharded x%d" % world, "objects": ARGS.objects,
             },
             "frames_per_s": ARGS.steps / dt,
             "pair_evals_per_s": 2.0 * P_total * M / (dt / ARGS.steps),
