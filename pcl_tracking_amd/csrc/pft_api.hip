@@ -65,6 +65,7 @@ struct pft_tracker {
   double* d_partial = nullptr;
   int32_t* d_alias_list = nullptr;
   double* d_alias_pref = nullptr;
+  double* d_pop_part = nullptr;
   uint32_t* d_alias_pos = nullptr;
   PftHeader* d_hdr = nullptr;
   int32_t* d_nn_idx = nullptr;
@@ -266,6 +267,7 @@ static void sync_dev(pft_tracker* t) {
   d.partial = t->d_partial;
   d.alias_list = t->d_alias_list;
   d.alias_pref = t->d_alias_pref;
+  d.pop_part = t->d_pop_part;
   d.alias_pos = t->d_alias_pos;
   d.hdr = t->d_hdr;
   d.nn_idx = t->d_nn_idx;
@@ -374,6 +376,7 @@ extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
   A(dalloc(&t->d_jump, (size_t)1 << (3 * PFT_JUMP_MAX_LEVEL)));
   A(dalloc(&t->d_alias_list, 2 * Pt));
   A(dalloc(&t->d_alias_pref, 2 * Pt));
+  A(dalloc(&t->d_pop_part, (size_t)PFT_POPM_MAX_WGS * 16));
   A(dalloc(&t->d_alias_pos, Pt));
   A(hipHostMalloc(reinterpret_cast<void**>(&t->h_stat), 4 * sizeof(uint32_t), hipHostMallocMapped));
   if (t->h_stat) t->h_stat[0] = t->h_stat[1] = 0;
@@ -421,7 +424,7 @@ extern "C" void pft_destroy(pft_tracker* t) {
   dfree(t->d_pt_key64); dfree(t->sort.keys[0]); dfree(t->sort.keys[1]); dfree(t->sort.vals[0]); dfree(t->sort.vals[1]);
   dfree(t->sort.hist); dfree(t->sort.tile_cnt); dfree(t->sort.tile_box); if (t->h_stat) hipHostFree(t->h_stat);
   dfree(t->d_partial); dfree(t->d_alias_list); dfree(t->d_alias_pos);
-  dfree(t->d_alias_pref); dfree(t->d_hdr); dfree(t->d_nn_idx); dfree(t->d_nn_d2); dfree(t->d_dbg_part);
+  dfree(t->d_alias_pref); dfree(t->d_pop_part); dfree(t->d_hdr); dfree(t->d_nn_idx); dfree(t->d_nn_d2); dfree(t->d_dbg_part);
   dfree(t->d_dbg_hdr); dfree(t->d_dbg_f);
   if (t->own_stream && t->stream) hipStreamDestroy(t->stream);
   delete t;
@@ -905,6 +908,7 @@ struct DbgPop {
 static int dbg_population(pft_tracker* t, std::vector<pft_particle>& host, int norm, int mean, int alias, DbgPop& b,
                           PftHeader* hout) {
   const size_t n = host.size();
+  if (n > PFT_MAX_PARTICLES) return PFT_ERR_CAPACITY;
   HIPCHK(t, dalloc(&b.part, n));
   HIPCHK(t, dalloc(&b.a, n));
   HIPCHK(t, dalloc(&b.q, n));

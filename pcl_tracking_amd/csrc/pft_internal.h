@@ -33,7 +33,11 @@
 #endif
 #define PFT_POP_THREADS 1024
 #define PFT_SORTED_BUILD_MIN 20000  // cropped points (last iteration) above which the sorted builder is used
-#define PFT_MAX_PARTICLES (64 * PFT_POP_THREADS)  // population kernel: <= 64 particles per thread
+#define PFT_POPM_THREADS 256
+#define PFT_POPM_ITEMS 16   // many-workgroup population path: 4096 particles per workgroup
+#define PFT_POPM_MAX_WGS 256
+#define PFT_POPM_MIN (16 * PFT_POP_THREADS + 1)  // above the register-resident single-workgroup range
+#define PFT_MAX_PARTICLES (PFT_POPM_MAX_WGS * PFT_POPM_THREADS * PFT_POPM_ITEMS)  // 1 048 576
 
 struct PftParams {  // immutable per handle, passed by value to kernels
   double alpha;
@@ -109,6 +113,7 @@ struct PftDev {  // device pointers (host-side struct, passed by value)
   int32_t* alias_list;   // [0,P): small list, [P,2P): large list
   double* alias_pref;    // [0,P): running deficit, [P,2P): running excess
   uint32_t* alias_pos;   // [P]
+  double* pop_part;      // [PFT_POPM_MAX_WGS][16] per-workgroup partials of the many-workgroup population path
   PftHeader* hdr;
   uint32_t* host_stat;  // pinned host memory, device-visible: [0] last n_crop, [1] last octree depth (read by the
                         // host WITHOUT synchronising, to pick the builder for the next iteration)

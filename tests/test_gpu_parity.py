@@ -231,7 +231,7 @@ def test_eval_weights_wide_spread_deep_tree(gpu, orc, data):
 
 
 # ---- A8, A9, A10 --------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n", [1, 2, 400, 1000, 8192, 65536])
+@pytest.mark.parametrize("n", [1, 2, 400, 1000, 8192, 16384, 16385, 40000, 65536, 300000])
 def test_normalize(gpu, orc, n):
     g = gpu.make_reference_tracker(particle_num=64)
     rng = np.random.default_rng(n)
@@ -246,7 +246,7 @@ def test_normalize(gpu, orc, n):
         np.testing.assert_array_equal(g.debugNormalize(special)[0], orc.normalize_weights(special)[0])
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 400, 1000, 8192, 65536])
+@pytest.mark.parametrize("n", [1, 2, 3, 400, 1000, 8192, 16384, 16385, 40000, 65536, 300000])
 def test_alias_table(gpu, orc, n):
     g = gpu.make_reference_tracker(particle_num=64)
     rng = np.random.default_rng(n + 1)
@@ -272,7 +272,7 @@ def test_alias_table(gpu, orc, n):
 
 def test_weighted_mean(gpu, orc, data):
     g = gpu.make_reference_tracker(particle_num=64)
-    for n in (1, 400, 8192):
+    for n in (1, 400, 8192, 40000, 65536):
         p = particles_around(data["gt"], n, n)
         w = np.random.default_rng(n).random(n).astype(np.float32)
         p["weight"] = w / w.sum()
