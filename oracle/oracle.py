@@ -36,10 +36,8 @@ class Config(C.Structure):
 
 def build(force=False):
     """Compile the C restatement with the committed Makefile (building the checker is not using it)."""
-    src = os.path.join(_HERE, "pft_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(
-        os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "pft_oracle.h"))
-    ):
+    srcs = [os.path.join(_HERE, f) for f in ("pft_oracle.c", "pft_oracle_filters.c", "pft_oracle.h", "Makefile")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
     return _SO
 
@@ -105,6 +103,12 @@ def lib():
     L.orc_tracker_set_matrix_override.argtypes = [vp, vp]
     L.orc_tracker_set_bbox_override.argtypes = [vp, vp]
     L.orc_tracker_set_bbox_only.argtypes = [vp, C.c_int]
+    L.orc_pass_through.argtypes = [vp, sz, C.c_int, f32, f32, C.c_int, vp]
+    L.orc_pass_through.restype = sz
+    L.orc_approx_voxel_grid.argtypes = [vp, sz, vp, u32, vp]
+    L.orc_approx_voxel_grid.restype = sz
+    L.orc_voxel_grid.argtypes = [vp, sz, vp, vp]
+    L.orc_voxel_grid.restype = sz
     _lib = L
     return L
 
@@ -261,6 +265,34 @@ def resample(cfg, old, a, q, rep, epoch, id_offset=0, n_local=None):
     lib().orc_resample(C.byref(cfg), _ptr(old), len(old), _ptr(a), _ptr(q), _ptr(rep), epoch, id_offset, n_local,
                        _ptr(out))
     return out
+
+
+def pass_through(pts, field="z", lo=0.0, hi=10.0, negative=False):
+    """PassThrough(field, [lo, hi]) -> indices kept (auto_tracking.cpp:536-547 uses z in [0, 10])"""
+    pts = np.ascontiguousarray(pts)
+    idx = np.zeros(len(pts), np.int32)
+    n = lib().orc_pass_through(_ptr(pts), len(pts), "xyz".index(field), lo, hi, int(negative), _ptr(idx))
+    return idx[:n].copy()
+
+
+def approx_voxel_grid(pts, leaf=0.01, hist_size=512):
+    """ApproximateVoxelGrid(leaf) (auto_tracking.cpp:563-575) -> output cloud"""
+    pts = np.ascontiguousarray(pts)
+    out = np.zeros(max(1, len(pts)), pts.dtype)
+    lf = np.asarray([leaf] * 3 if np.isscalar(leaf) else leaf, np.float32)
+    n = lib().orc_approx_voxel_grid(_ptr(pts), len(pts), _ptr(lf), hist_size, _ptr(out))
+    return out[:n].copy()
+
+
+def voxel_grid(pts, leaf=0.01):
+    """VoxelGrid(leaf) (auto_tracking.cpp:549-561) -> output cloud, or None when PCL would refuse the leaf size"""
+    pts = np.ascontiguousarray(pts)
+    out = np.zeros(max(1, len(pts)), pts.dtype)
+    lf = np.asarray([leaf] * 3 if np.isscalar(leaf) else leaf, np.float32)
+    n = lib().orc_voxel_grid(_ptr(pts), len(pts), _ptr(lf), _ptr(out))
+    if n == C.c_size_t(-1).value:
+        return None
+    return out[:n].copy()
 
 
 class Tracker:

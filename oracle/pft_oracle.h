@@ -147,6 +147,16 @@ size_t orc_tracker_eval_weights(orc_tracker_t* t, const orc_particle_t* particle
  * [3]=coherence [4]=normalize [5]=resample [6]=update */
 void orc_tracker_stage_times(const orc_tracker_t* t, double s[7]);
 
+/* ---- input filters in front of the tracker (pft_oracle_filters.c) ---- */
+/* PassThrough with a field name (0 = x, 1 = y, 2 = z), inclusive limits, keep_organized = false; returns #kept */
+size_t orc_pass_through(const orc_point_t* pts, size_t n, int field, float lo, float hi, int negative,
+                        int32_t* out_idx);
+/* ApproximateVoxelGrid (history table of hist_size entries, flush on collision); out: capacity n; returns #out */
+size_t orc_approx_voxel_grid(const orc_point_t* pts, size_t n, const float leaf[3], uint32_t hist_size,
+                             orc_point_t* out);
+/* VoxelGrid (exact, output sorted by voxel index; in-voxel summation in input order); returns #out or (size_t)-1 */
+size_t orc_voxel_grid(const orc_point_t* pts, size_t n, const float leaf[3], orc_point_t* out);
+
 #ifdef __cplusplus
 }
 #endif

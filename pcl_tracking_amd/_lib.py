@@ -35,7 +35,21 @@ class Config(C.Structure):
     ]
 
 
-# every symbol include/pft.h declares: (name, restype, argtypes)
+class FilterConfig(C.Structure):
+    """pft_filter_config (include/pft_filters.h)"""
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("device_id", C.c_int32), ("stream", C.c_void_p),
+        ("stream_is_external", C.c_int32),
+        ("pass_enable", C.c_int32), ("pass_field", C.c_int32), ("pass_min", C.c_float), ("pass_max", C.c_float),
+        ("pass_negative", C.c_int32),
+        ("voxel_mode", C.c_int32), ("leaf_size", C.c_float * 3), ("approx_hist_size", C.c_uint32),
+        ("max_points", C.c_uint32),
+    ]
+
+
+VOXEL_NONE, VOXEL_APPROX, VOXEL_EXACT = 0, 1, 2
+
+# every symbol include/*.h declare: (name, restype, argtypes)
 _vp, _sz, _i32, _u32, _u64, _f64 = C.c_void_p, C.c_size_t, C.c_int32, C.c_uint32, C.c_uint64, C.c_double
 _P = C.POINTER
 SYMBOLS = [
@@ -81,9 +95,45 @@ SYMBOLS = [
     ("pft_profile_get", C.c_int, [_vp, C.c_int, _P(_f64), _P(_u64)]),
     ("pft_profile_reset", C.c_int, [_vp]),
     ("pft_kernel_name", C.c_char_p, [C.c_int]),
+    # include/pft_filters.h
+    ("pft_filter_default_config", None, [_P(FilterConfig)]),
+    ("pft_filter_create", C.c_int, [_P(FilterConfig), _P(_vp)]),
+    ("pft_filter_destroy", None, [_vp]),
+    ("pft_filter_last_error_string", C.c_char_p, [_vp]),
+    ("pft_filter_apply", C.c_int, [_vp, _vp, _sz]),
+    ("pft_filter_apply_device", C.c_int, [_vp, _vp, _sz]),
+    ("pft_filter_counts", C.c_int, [_vp, _P(_sz), _P(_sz)]),
+    ("pft_filter_output_device", C.c_int, [_vp, _P(_vp), _P(_sz)]),
+    ("pft_filter_get_output", C.c_int, [_vp, _vp, _sz, _P(_sz)]),
+    ("pft_filter_get_pass_indices", C.c_int, [_vp, _vp, _sz, _P(_sz)]),
+    ("pft_filter_last_ms", C.c_int, [_vp, _P(_f64)]),
 ]
 
 _lib = None
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64;
+    libpft_hip.so asks for libamdhip64.so.7 by SONAME.  If torch is imported first the loader hands us
+    torch's copy and all is well; if we load /opt/rocm's copy first, torch later finds no GPU.  So when
+    PyTorch is installed (it is not imported here) its copy is loaded first, whatever the import order."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        try:
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def load():
@@ -95,6 +145,7 @@ def load():
         raise ImportError(
             "%s is missing: build it with `python -m pcl_tracking_amd.build` (hipcc, gfx950). "
             "pcl_tracking_amd has no CPU fallback." % LIB_PATH)
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
         f = getattr(L, name)  # AttributeError if the library does not export a declared symbol

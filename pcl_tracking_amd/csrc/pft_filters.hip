@@ -1,0 +1,779 @@
+// pft_filters.hip -- the per-frame input filters in front of the tracker (include/pft_filters.h):
+//   pcl::PassThrough            (PCL 1.8.0 filters/impl/passthrough.hpp;           auto_tracking.cpp:536-547)
+//   pcl::ApproximateVoxelGrid   (PCL 1.8.0 filters/impl/approximate_voxel_grid.hpp; auto_tracking.cpp:563-575)
+//   pcl::VoxelGrid              (PCL 1.8.0 filters/impl/voxel_grid.hpp;            auto_tracking.cpp:549-561)
+// as one chain of kernels on one HIP stream.  HBM-bound byte/integer work (N x 32 B in, a few N x 4 B
+// side arrays); at a 518 400-point frame the chain is launch-latency bound.
+//
+// ApproximateVoxelGrid is a SEQUENTIAL algorithm upstream: a small history table holds one open voxel per
+// hash entry, a point of another voxel that hashes to an occupied entry flushes it to the output, entries
+// still open at the end are flushed in table order.  Its output (which points are merged, float sums in
+// arrival order, output order) is reproduced exactly by observing that table entries are independent:
+//   1. stable-sort the points by hash entry (arrival order kept inside an entry);
+//   2. inside an entry a new run starts wherever the voxel (ix,iy,iz) changes: run = one output point,
+//      summed sequentially in arrival order by one thread;
+//   3. a run that is followed by another run in the same entry was flushed by that run's first point c:
+//      its output slot is the number of such "trigger" points before c in the input; the last run of
+//      entry h is flushed at the end: slot = #triggers + #non-empty entries below h.
+// VoxelGrid: bounds -> voxel index -> stable sort -> one CentroidPoint per run, output in index order.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+
+#include "pft_device_utils.h"
+#include "../../include/pft_filters.h"
+
+#define F_TILE 1024u
+#define F_THREADS 256
+#define F_BINS 256
+#define F_INVALID 0xFFFFFFFFu
+#define F_MAX_HIST 2048u
+
+struct FParams {
+  uint32_t n;
+  int pass_enable, pass_field, pass_negative;
+  float pass_min, pass_max;
+  float inv[3];
+  uint32_t hist_mask;
+  int mode;
+};
+
+struct FHdr {
+  uint32_t n_pass, n_out, n_trig, n_present;
+  int32_t minb[3], div[3], mul[3];
+  int32_t leaf_too_small;
+};
+
+struct FDev {
+  const pft_point_xyzrgba* in;
+  pft_point_xyzrgba* out;
+  uint32_t* key[2];
+  uint32_t* val[2];
+  int4* cell;
+  uint8_t* passf;
+  uint8_t* trig;
+  uint8_t* head;
+  uint32_t* trig_pos;
+  uint32_t* hist;
+  uint32_t* tile_trig;
+  uint32_t* tile_pass;
+  uint32_t* tile_head;
+  uint32_t* bucket;  // [F_MAX_HIST + 1]: present flag, then rank
+  float* bpart;      // [ntiles][6]
+  int32_t* pass_idx;
+  FHdr* hdr;
+  uint32_t* host_stat;
+};
+
+// static_cast<int>(floor(v)) as x86 evaluates it (cvttss2si: NaN / out of range -> INT_MIN)
+__device__ __forceinline__ int floor_to_int(float v) {
+  const float f = floorf(v);
+  if (!(f >= -2147483648.0f && f < 2147483648.0f)) return (int)0x80000000;
+  return (int)f;
+}
+
+__device__ __forceinline__ bool finite3(float x, float y, float z) {
+  return __builtin_isfinite(x) && __builtin_isfinite(y) && __builtin_isfinite(z);
+}
+
+__device__ __forceinline__ bool f_passes(const FParams& p, float x, float y, float z) {
+  if (!p.pass_enable) return true;
+  if (!finite3(x, y, z)) return false;
+  const float v = p.pass_field == 0 ? x : (p.pass_field == 1 ? y : z);
+  if (!p.pass_negative) return !(v < p.pass_min || v > p.pass_max);
+  return !(v >= p.pass_min && v <= p.pass_max);
+}
+
+// ---- stage 1: PassThrough decision, voxel / hash of every point, per-tile counts (and bounds) ----
+__global__ __launch_bounds__(F_THREADS) void k_f_classify(FParams p, FDev d) {
+  __shared__ uint32_t su[20];
+  __shared__ float sf[6][20];
+  const uint32_t t = blockIdx.x, tid = threadIdx.x;
+  if (t == 0)
+    for (uint32_t b = tid; b <= F_MAX_HIST; b += F_THREADS) d.bucket[b] = 0;
+  if (tid == 0) {
+    d.tile_trig[t] = 0;
+    d.tile_head[t] = 0;
+  }
+  uint32_t cnt = 0;
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int k = 0; k < 4; k++) {
+    const uint32_t i = t * F_TILE + k * F_THREADS + tid;
+    if (i >= p.n) break;
+    const float4 q = *reinterpret_cast<const float4*>(d.in + i);
+    bool pass = f_passes(p, q.x, q.y, q.z);
+    uint32_t kk = F_INVALID;
+    if (p.mode == PFT_VOXEL_APPROX) {
+      if (pass) {
+        const int ix = floor_to_int(q.x * p.inv[0]);
+        const int iy = floor_to_int(q.y * p.inv[1]);
+        const int iz = floor_to_int(q.z * p.inv[2]);
+        kk = ((uint32_t)ix * 7171u + (uint32_t)iy * 3079u + (uint32_t)iz * 4231u) & p.hist_mask;
+        d.cell[i] = make_int4(ix, iy, iz, (int)kk);
+      }
+    } else if (p.mode == PFT_VOXEL_EXACT) {
+      pass = pass && finite3(q.x, q.y, q.z);  // the grid skips non-finite points (is_dense == false)
+      if (pass) {
+        mn[0] = fminf(mn[0], q.x); mn[1] = fminf(mn[1], q.y); mn[2] = fminf(mn[2], q.z);
+        mx[0] = fmaxf(mx[0], q.x); mx[1] = fmaxf(mx[1], q.y); mx[2] = fmaxf(mx[2], q.z);
+      }
+    } else if (pass) {
+      kk = 0;
+    }
+    d.key[0][i] = kk;
+    d.val[0][i] = i;
+    d.passf[i] = pass ? 1 : 0;
+    d.trig[i] = 0;
+    cnt += pass ? 1u : 0u;
+  }
+  uint32_t tot;
+  block_excl_scan<uint32_t>(cnt, su, &tot);
+  if (tid == 0) d.tile_pass[t] = tot;
+  if (p.mode == PFT_VOXEL_EXACT) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const float lo = block_reduce<float>(mn[a], sf[a], OpMinF(), INFINITY);
+      const float hi = block_reduce<float>(mx[a], sf[3 + a], OpMaxF(), -INFINITY);
+      if (tid == 0) {
+        d.bpart[t * 6 + a] = lo;
+        d.bpart[t * 6 + 3 + a] = hi;
+      }
+    }
+  }
+}
+
+// VoxelGrid: getMinMax3D over the tiles, min_b / div_b / divb_mul and the "leaf size too small" test
+__global__ __launch_bounds__(F_THREADS) void k_f_bounds(FParams p, FDev d, uint32_t ntiles) {
+  __shared__ float sf[6][20];
+  const uint32_t tid = threadIdx.x;
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (uint32_t t = tid; t < ntiles; t += F_THREADS)
+    for (int a = 0; a < 3; a++) {
+      mn[a] = fminf(mn[a], d.bpart[t * 6 + a]);
+      mx[a] = fmaxf(mx[a], d.bpart[t * 6 + 3 + a]);
+    }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    mn[a] = block_reduce<float>(mn[a], sf[a], OpMinF(), INFINITY);
+    mx[a] = block_reduce<float>(mx[a], sf[3 + a], OpMaxF(), -INFINITY);
+  }
+  if (tid == 0) {
+    FHdr* h = d.hdr;
+    h->leaf_too_small = 0;
+    if (mn[0] <= mx[0]) {
+      long long dd[3];
+      for (int a = 0; a < 3; a++) dd[a] = (long long)((mx[a] - mn[a]) * p.inv[a]) + 1;
+      // the three factors are <= 2^31 each in every case that passes; checked stepwise to stay inside 64 bits
+      const bool too_small = dd[0] > 0x7fffffffLL || dd[1] > 0x7fffffffLL || dd[2] > 0x7fffffffLL ||
+                             dd[0] * dd[1] > 0x7fffffffLL || dd[0] * dd[1] * dd[2] > 0x7fffffffLL;
+      h->leaf_too_small = too_small ? 1 : 0;
+      for (int a = 0; a < 3; a++) {
+        h->minb[a] = floor_to_int(mn[a] * p.inv[a]);
+        h->div[a] = floor_to_int(mx[a] * p.inv[a]) - h->minb[a] + 1;
+      }
+      h->mul[0] = 1;
+      h->mul[1] = h->div[0];
+      h->mul[2] = h->div[0] * h->div[1];
+    }
+  }
+}
+
+__global__ __launch_bounds__(F_THREADS) void k_f_keys_exact(FParams p, FDev d) {
+  const uint32_t i = blockIdx.x * F_THREADS + threadIdx.x;
+  if (i >= p.n || !d.passf[i]) return;
+  const FHdr* h = d.hdr;
+  if (h->leaf_too_small) return;
+  const float4 q = *reinterpret_cast<const float4*>(d.in + i);
+  const int i0 = (int)(floorf(q.x * p.inv[0]) - (float)h->minb[0]);
+  const int i1 = (int)(floorf(q.y * p.inv[1]) - (float)h->minb[1]);
+  const int i2 = (int)(floorf(q.z * p.inv[2]) - (float)h->minb[2]);
+  d.key[0][i] = (uint32_t)(i0 * h->mul[0] + i1 * h->mul[1] + i2 * h->mul[2]);
+}
+
+// ---- stable LSD radix sort of (key, val), 8-bit digit, one wave per 1024-element tile ----
+__global__ __launch_bounds__(64) void k_f_rs_hist(const uint32_t* __restrict__ keys, uint32_t n, int shift,
+                                                  uint32_t* __restrict__ hist, uint32_t ntiles) {
+  __shared__ uint32_t h[F_BINS];
+  const uint32_t t = blockIdx.x, lane = threadIdx.x;
+  for (int b = lane; b < F_BINS; b += 64) h[b] = 0;
+  __syncthreads();
+  const uint32_t base = t * F_TILE;
+#pragma unroll 4
+  for (uint32_t c = 0; c < F_TILE / 64; c++) {
+    const uint32_t i = base + c * 64 + lane;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & 0xffu], 1u);
+  }
+  __syncthreads();
+  for (int b = lane; b < F_BINS; b += 64) hist[(size_t)b * ntiles + t] = h[b];
+}
+
+__global__ __launch_bounds__(F_THREADS) void k_f_rs_scan(uint32_t* __restrict__ hist, uint32_t ntiles) {
+  __shared__ uint32_t scr[20];
+  const uint32_t b = blockIdx.x, tid = threadIdx.x;
+  uint32_t* row = hist + (size_t)b * ntiles;
+  uint32_t carry = 0;
+  for (uint32_t t0 = 0; t0 < ntiles; t0 += F_THREADS) {
+    const uint32_t t = t0 + tid;
+    const uint32_t v = t < ntiles ? row[t] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan<uint32_t>(v, scr, &tot);
+    if (t < ntiles) row[t] = carry + ex;
+    carry += tot;
+  }
+  if (tid == 0) hist[(size_t)F_BINS * ntiles + b] = carry;
+}
+
+__global__ __launch_bounds__(64) void k_f_rs_scatter(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                     uint32_t* __restrict__ kout, uint32_t* __restrict__ vout, uint32_t n,
+                                                     int shift, const uint32_t* __restrict__ offs, uint32_t ntiles) {
+  const uint32_t t = blockIdx.x, lane = threadIdx.x;
+  const uint32_t base = t * F_TILE;
+  __shared__ uint32_t cnt[F_BINS];
+  {  // bin bases = exclusive scan of the 256 bin totals (4 consecutive bins per lane) + this tile's offset in the bin
+    const uint32_t* tot = offs + (size_t)F_BINS * ntiles;
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      v[k] = tot[lane * 4 + k];
+      sum += v[k];
+    }
+    uint32_t run = wave_incl_scan(sum) - sum;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      cnt[lane * 4 + k] = run + offs[(size_t)(lane * 4 + k) * ntiles + t];
+      run += v[k];
+    }
+  }
+  __syncthreads();
+  for (uint32_t c = 0; c < F_TILE / 64; c++) {
+    const uint32_t i = base + c * 64 + lane;
+    const bool valid = i < n;
+    const uint32_t key = valid ? kin[i] : 0u;
+    const uint32_t val = valid ? vin[i] : 0u;
+    const uint32_t dig = (key >> shift) & 0xffu;
+    // peers = lanes of this chunk with the same digit; lanes past the end form their own class
+    unsigned long long peers = __ballot(valid);
+    if (!valid) peers = ~peers;
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const unsigned long long m = __ballot((dig >> b) & 1u);
+      peers &= ((dig >> b) & 1u) ? m : ~m;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t rank = __popcll(peers & lt);
+    const uint32_t dst0 = cnt[dig];
+    __builtin_amdgcn_wave_barrier();
+    if (valid && rank == 0) cnt[dig] = dst0 + (uint32_t)__popcll(peers);  // leader advances the running offset
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (valid) {
+      kout[dst0 + rank] = key;
+      vout[dst0 + rank] = val;
+    }
+  }
+}
+
+// ---- ApproximateVoxelGrid: run heads and flush triggers in table-entry order ----
+__global__ __launch_bounds__(F_THREADS) void k_f_heads_approx(FParams p, FDev d, const uint32_t* __restrict__ skey,
+                                                              const uint32_t* __restrict__ sval) {
+  const uint32_t j = blockIdx.x * F_THREADS + threadIdx.x;
+  if (j >= p.n) return;
+  const uint32_t k = skey[j];
+  if (k == F_INVALID) {
+    d.head[j] = 0;
+    return;
+  }
+  const uint32_t v = sval[j];
+  bool first = true, head = true;
+  if (j > 0 && skey[j - 1] == k) {
+    first = false;
+    const int4 c = d.cell[v], q = d.cell[sval[j - 1]];
+    head = (c.x != q.x) || (c.y != q.y) || (c.z != q.z);
+  }
+  d.head[j] = head ? 1 : 0;
+  if (first) d.bucket[k] = 1;
+  if (head && !first) {  // v is the point whose arrival flushed the previous run of this entry
+    d.trig[v] = 1;
+    atomicAdd(&d.tile_trig[v / F_TILE], 1u);
+  }
+}
+
+// VoxelGrid: run heads in sorted order, per-tile head counts
+__global__ __launch_bounds__(F_THREADS) void k_f_heads_exact(FParams p, FDev d, const uint32_t* __restrict__ skey) {
+  __shared__ uint32_t su[20];
+  const uint32_t t = blockIdx.x, tid = threadIdx.x;
+  uint32_t cnt = 0;
+  for (int k = 0; k < 4; k++) {
+    const uint32_t j = t * F_TILE + k * F_THREADS + tid;
+    if (j >= p.n) break;
+    const uint32_t key = skey[j];
+    const bool head = key != F_INVALID && (j == 0 || skey[j - 1] != key);
+    d.head[j] = head ? 1 : 0;
+    cnt += head ? 1u : 0u;
+  }
+  uint32_t tot;
+  block_excl_scan<uint32_t>(cnt, su, &tot);
+  if (tid == 0) d.tile_head[t] = tot;
+}
+
+// in-place exclusive scan of a[0..n) by one workgroup; returns the total to every thread
+__device__ uint32_t scan_array(uint32_t* a, uint32_t n, uint32_t* scr) {
+  uint32_t carry = 0;
+  for (uint32_t t0 = 0; t0 < n; t0 += blockDim.x) {
+    const uint32_t t = t0 + threadIdx.x;
+    const uint32_t v = t < n ? a[t] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan<uint32_t>(v, scr, &tot);
+    if (t < n) a[t] = carry + ex;
+    carry += tot;
+  }
+  return carry;
+}
+
+// one workgroup: the small scans (per-tile counts, table-entry ranks) and the output counts
+__global__ __launch_bounds__(1024) void k_f_scan_small(FParams p, FDev d, uint32_t ntiles) {
+  __shared__ uint32_t scr[20];
+  const uint32_t n_pass = scan_array(d.tile_pass, ntiles, scr);
+  uint32_t n_out = n_pass, n_trig = 0, n_present = 0;
+  if (p.mode == PFT_VOXEL_APPROX) {
+    n_trig = scan_array(d.tile_trig, ntiles, scr);
+    n_present = scan_array(d.bucket, p.hist_mask + 1u, scr);
+    n_out = n_trig + n_present;
+  } else if (p.mode == PFT_VOXEL_EXACT) {
+    n_out = scan_array(d.tile_head, ntiles, scr);
+    if (d.hdr->leaf_too_small) n_out = 0;
+  }
+  if (threadIdx.x == 0) {
+    d.hdr->n_pass = n_pass;
+    d.hdr->n_out = n_out;
+    d.hdr->n_trig = n_trig;
+    d.hdr->n_present = n_present;
+    d.host_stat[0] = n_pass;
+    d.host_stat[1] = n_out;
+    d.host_stat[2] = (uint32_t)d.hdr->leaf_too_small;
+  }
+}
+
+// exclusive rank of every trigger point in input order
+__global__ __launch_bounds__(F_THREADS) void k_f_trig_pos(FParams p, FDev d) {
+  __shared__ uint32_t su[20];
+  const uint32_t t = blockIdx.x, tid = threadIdx.x;
+  const uint32_t i0 = t * F_TILE + tid * 4;
+  uint32_t f[4], cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    f[k] = (i0 + k < p.n) ? d.trig[i0 + k] : 0u;
+    cnt += f[k];
+  }
+  uint32_t tot;
+  uint32_t ex = d.tile_trig[t] + block_excl_scan<uint32_t>(cnt, su, &tot);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (i0 + k < p.n) d.trig_pos[i0 + k] = ex;
+    ex += f[k];
+  }
+}
+
+__device__ __forceinline__ void store_point(pft_point_xyzrgba* o, float x, float y, float z, uint32_t rgba) {
+  float4* q = reinterpret_cast<float4*>(o);
+  q[0] = make_float4(x, y, z, 1.0f);
+  q[1] = make_float4(__uint_as_float(rgba), 0.0f, 0.0f, 0.0f);
+}
+
+// one thread per run: the centroid in arrival order (flush()), written to its flush slot
+__global__ __launch_bounds__(F_THREADS) void k_f_emit_approx(FParams p, FDev d, const uint32_t* __restrict__ skey,
+                                                             const uint32_t* __restrict__ sval) {
+  const uint32_t j = blockIdx.x * F_THREADS + threadIdx.x;
+  if (j >= p.n || !d.head[j]) return;
+  const uint32_t b = skey[j];
+  float sx = 0.0f, sy = 0.0f, sz = 0.0f, sr = 0.0f, sg = 0.0f, sb = 0.0f;
+  uint32_t e = j, count = 0;
+  do {
+    const float4* q = reinterpret_cast<const float4*>(d.in + sval[e]);
+    const float4 a = q[0];
+    const uint32_t rgba = __float_as_uint(q[1].x);
+    sx += a.x;
+    sy += a.y;
+    sz += a.z;
+    sr += (float)((rgba >> 16) & 255u);
+    sg += (float)((rgba >> 8) & 255u);
+    sb += (float)(rgba & 255u);
+    count++;
+    e++;
+  } while (e < p.n && skey[e] == b && !d.head[e]);
+  const float cnt = (float)count;
+  const int rgb = ((int)(sr / cnt)) << 16 | ((int)(sg / cnt)) << 8 | ((int)(sb / cnt));
+  uint32_t pos;
+  if (e < p.n && skey[e] == b)
+    pos = d.trig_pos[sval[e]];  // flushed when the next run of this entry arrived
+  else
+    pos = d.hdr->n_trig + d.bucket[b];  // still open at the end: flushed in table order
+  store_point(d.out + pos, sx / cnt, sy / cnt, sz / cnt, (uint32_t)rgb);
+}
+
+// VoxelGrid: one CentroidPoint per voxel, output in voxel-index order
+__global__ __launch_bounds__(F_THREADS) void k_f_emit_exact(FParams p, FDev d, const uint32_t* __restrict__ skey,
+                                                            const uint32_t* __restrict__ sval) {
+  __shared__ uint32_t su[20];
+  const uint32_t t = blockIdx.x, tid = threadIdx.x;
+  const uint32_t j0 = t * F_TILE + tid * 4;
+  uint32_t f[4], cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    f[k] = (j0 + k < p.n) ? d.head[j0 + k] : 0u;
+    cnt += f[k];
+  }
+  uint32_t tot;
+  uint32_t pos = d.tile_head[t] + block_excl_scan<uint32_t>(cnt, su, &tot);
+  if (d.hdr->leaf_too_small) return;
+  for (int k = 0; k < 4; k++) {
+    if (!f[k]) continue;
+    const uint32_t j = j0 + k, b = skey[j];
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f, sr = 0.0f, sg = 0.0f, sb = 0.0f, sa = 0.0f;
+    uint32_t e = j, count = 0;
+    do {
+      const float4* q = reinterpret_cast<const float4*>(d.in + sval[e]);
+      const float4 a = q[0];
+      const uint32_t rgba = __float_as_uint(q[1].x);
+      sx += a.x;
+      sy += a.y;
+      sz += a.z;
+      sr += (float)((rgba >> 16) & 255u);
+      sg += (float)((rgba >> 8) & 255u);
+      sb += (float)(rgba & 255u);
+      sa += (float)(rgba >> 24);
+      count++;
+      e++;
+    } while (e < p.n && skey[e] == b);
+    const float c = (float)count;
+    const uint32_t rgba = (uint32_t)(sa / c) << 24 | (uint32_t)(sr / c) << 16 | (uint32_t)(sg / c) << 8 | (uint32_t)(sb / c);
+    store_point(d.out + pos, sx / c, sy / c, sz / c, rgba);
+    pos++;
+  }
+}
+
+// PassThrough alone: the kept points, stable (sorted position j < n_pass holds input index sval[j])
+__global__ __launch_bounds__(F_THREADS) void k_f_gather(FParams p, FDev d, const uint32_t* __restrict__ sval) {
+  const uint32_t j = blockIdx.x * F_THREADS + threadIdx.x;
+  if (j >= d.hdr->n_pass) return;
+  const float4* q = reinterpret_cast<const float4*>(d.in + sval[j]);
+  float4* o = reinterpret_cast<float4*>(d.out + j);
+  o[0] = q[0];
+  o[1] = q[1];
+}
+
+// indices kept by PassThrough, in input order (pcl::PassThrough::filter(std::vector<int>&))
+__global__ __launch_bounds__(F_THREADS) void k_f_pass_indices(FParams p, FDev d) {
+  __shared__ uint32_t su[20];
+  const uint32_t t = blockIdx.x, tid = threadIdx.x;
+  const uint32_t i0 = t * F_TILE + tid * 4;
+  uint32_t f[4], cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    f[k] = (i0 + k < p.n) ? d.passf[i0 + k] : 0u;
+    cnt += f[k];
+  }
+  uint32_t tot;
+  uint32_t ex = d.tile_pass[t] + block_excl_scan<uint32_t>(cnt, su, &tot);
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (f[k]) d.pass_idx[ex++] = (int32_t)(i0 + k);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+#define FCHK(f, call)                                                  \
+  do {                                                                 \
+    hipError_t e_ = (call);                                            \
+    if (e_ != hipSuccess) {                                            \
+      (f)->err = std::string(#call) + ": " + hipGetErrorString(e_);    \
+      return PFT_ERR_HIP;                                              \
+    }                                                                  \
+  } while (0)
+
+struct pft_filter {
+  pft_filter_config cfg;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  size_t cap = 0;
+  uint32_t ntiles = 0;
+  pft_point_xyzrgba* d_in_own = nullptr;
+  FDev d = {};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  size_t n_in = 0, n_pass = 0, n_out = 0;
+  int leaf_too_small = 0;
+  bool have_result = false;
+  double last_ms = 0.0;
+};
+
+template <typename T>
+static hipError_t falloc(T** p, size_t n) {
+  return hipMalloc(reinterpret_cast<void**>(p), (n ? n : 1) * sizeof(T));
+}
+template <typename T>
+static void ffree(T*& p) {
+  if (p) hipFree((void*)p);
+  p = nullptr;
+}
+
+static void free_buffers(pft_filter* f) {
+  FDev& d = f->d;
+  ffree(f->d_in_own); ffree(d.out); ffree(d.key[0]); ffree(d.key[1]); ffree(d.val[0]); ffree(d.val[1]);
+  ffree(d.cell); ffree(d.passf); ffree(d.trig); ffree(d.head); ffree(d.trig_pos); ffree(d.hist);
+  ffree(d.tile_trig); ffree(d.tile_pass); ffree(d.tile_head); ffree(d.bpart); ffree(d.pass_idx);
+  f->cap = 0;
+}
+
+static int ensure_capacity(pft_filter* f, size_t n) {
+  if (n <= f->cap) return PFT_OK;
+  if (f->stream) FCHK(f, hipStreamSynchronize(f->stream));
+  free_buffers(f);
+  size_t cap = n < 1024 ? 1024 : n;
+  cap = (cap + 1023) / 1024 * 1024;
+  const uint32_t nt = (uint32_t)(cap / 1024);
+  FDev& d = f->d;
+  FCHK(f, falloc(&f->d_in_own, cap));
+  FCHK(f, falloc(&d.out, cap));
+  for (int k = 0; k < 2; k++) {
+    FCHK(f, falloc(&d.key[k], cap));
+    FCHK(f, falloc(&d.val[k], cap));
+  }
+  FCHK(f, falloc(&d.cell, cap));
+  FCHK(f, falloc(&d.passf, cap));
+  FCHK(f, falloc(&d.trig, cap + 4));
+  FCHK(f, falloc(&d.head, cap + 4));
+  FCHK(f, falloc(&d.trig_pos, cap));
+  FCHK(f, falloc(&d.hist, (size_t)F_BINS * nt + F_BINS));
+  FCHK(f, falloc(&d.tile_trig, nt));
+  FCHK(f, falloc(&d.tile_pass, nt));
+  FCHK(f, falloc(&d.tile_head, nt));
+  FCHK(f, falloc(&d.bpart, (size_t)nt * 6));
+  FCHK(f, falloc(&d.pass_idx, cap));
+  f->cap = cap;
+  return PFT_OK;
+}
+
+extern "C" void pft_filter_default_config(pft_filter_config* c) {
+  if (!c) return;
+  memset(c, 0, sizeof(*c));
+  c->abi_version = PFT_ABI_VERSION;
+  c->pass_enable = 1;  // auto_tracking.cpp:536-547
+  c->pass_field = 2;
+  c->pass_min = 0.0f;
+  c->pass_max = 10.0f;
+  c->voxel_mode = PFT_VOXEL_APPROX;  // auto_tracking.cpp:563-575
+  c->leaf_size[0] = c->leaf_size[1] = c->leaf_size[2] = 0.01f;
+  c->approx_hist_size = 512;  // PCL 1.8.0 approximate_voxel_grid.h: histsize_ (512)
+  c->max_points = 960 * 540;  // Kinect2 qhd, auto_tracking.cpp:775
+}
+
+extern "C" int pft_filter_create(const pft_filter_config* cfg, pft_filter** out) {
+  if (!cfg || !out) return PFT_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (cfg->abi_version != PFT_ABI_VERSION) return PFT_ERR_INVALID_ARG;
+  if (cfg->pass_field < 0 || cfg->pass_field > 2) return PFT_ERR_INVALID_ARG;
+  if (cfg->voxel_mode < PFT_VOXEL_NONE || cfg->voxel_mode > PFT_VOXEL_EXACT) return PFT_ERR_INVALID_ARG;
+  if (cfg->voxel_mode != PFT_VOXEL_NONE)
+    for (int k = 0; k < 3; k++)
+      if (!(cfg->leaf_size[k] > 0.0f)) return PFT_ERR_INVALID_ARG;
+  const uint32_t hs = cfg->approx_hist_size;
+  if (cfg->voxel_mode == PFT_VOXEL_APPROX && (hs == 0 || (hs & (hs - 1)) || hs > F_MAX_HIST)) return PFT_ERR_INVALID_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PFT_ERR_NO_DEVICE;  // no CPU path
+  if (cfg->device_id < 0 || cfg->device_id >= ndev) return PFT_ERR_INVALID_ARG;
+  if (hipSetDevice(cfg->device_id) != hipSuccess) return PFT_ERR_NO_DEVICE;
+  pft_filter* f = new pft_filter();
+  f->cfg = *cfg;
+  if (cfg->stream_is_external) {
+    f->stream = reinterpret_cast<hipStream_t>(cfg->stream);
+  } else {
+    if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete f;
+      return PFT_ERR_HIP;
+    }
+    f->own_stream = true;
+  }
+  bool ok = hipEventCreate(&f->ev0) == hipSuccess && hipEventCreate(&f->ev1) == hipSuccess &&
+            falloc(&f->d.bucket, F_MAX_HIST + 1) == hipSuccess && falloc(&f->d.hdr, 1) == hipSuccess &&
+            hipHostMalloc(reinterpret_cast<void**>(&f->d.host_stat), 4 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess;
+  if (ok) ok = hipMemset(f->d.hdr, 0, sizeof(FHdr)) == hipSuccess;
+  if (ok) ok = ensure_capacity(f, cfg->max_points ? cfg->max_points : 1024) == PFT_OK;
+  if (!ok) {
+    pft_filter_destroy(f);
+    return PFT_ERR_HIP;
+  }
+  *out = f;
+  return PFT_OK;
+}
+
+extern "C" void pft_filter_destroy(pft_filter* f) {
+  if (!f) return;
+  if (f->stream) hipStreamSynchronize(f->stream);
+  free_buffers(f);
+  ffree(f->d.bucket);
+  ffree(f->d.hdr);
+  if (f->d.host_stat) hipHostFree(f->d.host_stat);
+  if (f->ev0) hipEventDestroy(f->ev0);
+  if (f->ev1) hipEventDestroy(f->ev1);
+  if (f->own_stream && f->stream) hipStreamDestroy(f->stream);
+  delete f;
+}
+
+extern "C" const char* pft_filter_last_error_string(const pft_filter* f) { return f ? f->err.c_str() : "null handle"; }
+
+static int run_pipeline(pft_filter* f, const pft_point_xyzrgba* d_in, size_t n) {
+  const pft_filter_config& c = f->cfg;
+  hipStream_t s = f->stream;
+  FDev d = f->d;
+  d.in = d_in;
+  FParams p;
+  p.n = (uint32_t)n;
+  p.pass_enable = c.pass_enable;
+  p.pass_field = c.pass_field;
+  p.pass_negative = c.pass_negative;
+  p.pass_min = c.pass_min;
+  p.pass_max = c.pass_max;
+  // setLeafSize: inverse_leaf_size_ = Eigen::Array3f::Ones() / leaf_size_.array()  (float division on the host)
+  for (int k = 0; k < 3; k++) p.inv[k] = c.voxel_mode != PFT_VOXEL_NONE ? 1.0f / c.leaf_size[k] : 0.0f;
+  p.hist_mask = c.approx_hist_size ? c.approx_hist_size - 1u : 0u;
+  p.mode = c.voxel_mode;
+  const uint32_t ntiles = (uint32_t)((n + F_TILE - 1) / F_TILE);
+  const uint32_t nblk = (uint32_t)((n + F_THREADS - 1) / F_THREADS);
+  f->ntiles = ntiles;
+  FCHK(f, hipEventRecord(f->ev0, s));
+  hipLaunchKernelGGL(k_f_classify, dim3(ntiles), dim3(F_THREADS), 0, s, p, d);
+  int npass = 1;
+  if (p.mode == PFT_VOXEL_APPROX) npass = 2;  // keys < 2048, invalid = 0xFFFFFFFF: bits 0..15 order them
+  if (p.mode == PFT_VOXEL_EXACT) {
+    npass = 4;
+    hipLaunchKernelGGL(k_f_bounds, dim3(1), dim3(F_THREADS), 0, s, p, d, ntiles);
+    hipLaunchKernelGGL(k_f_keys_exact, dim3(nblk), dim3(F_THREADS), 0, s, p, d);
+  }
+  int cur = 0;
+  for (int pass = 0; pass < npass; pass++) {
+    const int shift = 8 * pass;
+    hipLaunchKernelGGL(k_f_rs_hist, dim3(ntiles), dim3(64), 0, s, d.key[cur], p.n, shift, d.hist, ntiles);
+    hipLaunchKernelGGL(k_f_rs_scan, dim3(F_BINS), dim3(F_THREADS), 0, s, d.hist, ntiles);
+    hipLaunchKernelGGL(k_f_rs_scatter, dim3(ntiles), dim3(64), 0, s, d.key[cur], d.val[cur], d.key[1 - cur],
+                       d.val[1 - cur], p.n, shift, d.hist, ntiles);
+    cur = 1 - cur;
+  }
+  const uint32_t* skey = d.key[cur];
+  const uint32_t* sval = d.val[cur];
+  if (p.mode == PFT_VOXEL_APPROX) {
+    hipLaunchKernelGGL(k_f_heads_approx, dim3(nblk), dim3(F_THREADS), 0, s, p, d, skey, sval);
+    hipLaunchKernelGGL(k_f_scan_small, dim3(1), dim3(1024), 0, s, p, d, ntiles);
+    hipLaunchKernelGGL(k_f_trig_pos, dim3(ntiles), dim3(F_THREADS), 0, s, p, d);
+    hipLaunchKernelGGL(k_f_emit_approx, dim3(nblk), dim3(F_THREADS), 0, s, p, d, skey, sval);
+  } else if (p.mode == PFT_VOXEL_EXACT) {
+    hipLaunchKernelGGL(k_f_heads_exact, dim3(ntiles), dim3(F_THREADS), 0, s, p, d, skey);
+    hipLaunchKernelGGL(k_f_scan_small, dim3(1), dim3(1024), 0, s, p, d, ntiles);
+    hipLaunchKernelGGL(k_f_emit_exact, dim3(ntiles), dim3(F_THREADS), 0, s, p, d, skey, sval);
+  } else {
+    hipLaunchKernelGGL(k_f_scan_small, dim3(1), dim3(1024), 0, s, p, d, ntiles);
+    hipLaunchKernelGGL(k_f_gather, dim3(nblk), dim3(F_THREADS), 0, s, p, d, sval);
+  }
+  FCHK(f, hipEventRecord(f->ev1, s));
+  FCHK(f, hipGetLastError());
+  FCHK(f, hipStreamSynchronize(s));
+  float ms = 0.0f;
+  FCHK(f, hipEventElapsedTime(&ms, f->ev0, f->ev1));
+  f->last_ms = ms;
+  f->n_in = n;
+  f->n_pass = f->d.host_stat[0];
+  f->n_out = f->d.host_stat[1];
+  f->leaf_too_small = (int)f->d.host_stat[2];
+  f->have_result = true;
+  if (f->leaf_too_small) {
+    // PCL warns "Leaf size is too small for the input dataset" and hands the input cloud through unchanged
+    FCHK(f, hipMemcpyAsync(f->d.out, d_in, n * sizeof(pft_point_xyzrgba), hipMemcpyDeviceToDevice, s));
+    FCHK(f, hipStreamSynchronize(s));
+    f->n_out = n;
+  }
+  return PFT_OK;
+}
+
+static int apply_common(pft_filter* f, const pft_point_xyzrgba* pts, size_t n, bool on_device) {
+  if (!f || (!pts && n)) return PFT_ERR_INVALID_ARG;
+  if (n > 0x7fffffffu) return PFT_ERR_CAPACITY;
+  f->have_result = false;
+  FCHK(f, hipSetDevice(f->cfg.device_id));
+  if (n == 0) {  // empty input cloud: empty output
+    f->n_in = f->n_pass = f->n_out = 0;
+    f->leaf_too_small = 0;
+    f->last_ms = 0.0;
+    f->have_result = true;
+    return PFT_OK;
+  }
+  int r = ensure_capacity(f, n);
+  if (r != PFT_OK) return r;
+  const pft_point_xyzrgba* d_in = pts;
+  if (!on_device) {
+    FCHK(f, hipMemcpyAsync(f->d_in_own, pts, n * sizeof(pft_point_xyzrgba), hipMemcpyHostToDevice, f->stream));
+    d_in = f->d_in_own;
+  }
+  return run_pipeline(f, d_in, n);
+}
+
+extern "C" int pft_filter_apply(pft_filter* f, const pft_point_xyzrgba* host_points, size_t n) {
+  return apply_common(f, host_points, n, false);
+}
+
+extern "C" int pft_filter_apply_device(pft_filter* f, const pft_point_xyzrgba* device_points, size_t n) {
+  return apply_common(f, device_points, n, true);
+}
+
+extern "C" int pft_filter_counts(const pft_filter* f, size_t* n_pass, size_t* n_out) {
+  if (!f) return PFT_ERR_INVALID_ARG;
+  if (!f->have_result) return PFT_ERR_STATE;
+  if (n_pass) *n_pass = f->n_pass;
+  if (n_out) *n_out = f->n_out;
+  return PFT_OK;
+}
+
+extern "C" int pft_filter_output_device(const pft_filter* f, const pft_point_xyzrgba** device_points, size_t* n_out) {
+  if (!f || !device_points || !n_out) return PFT_ERR_INVALID_ARG;
+  if (!f->have_result) return PFT_ERR_STATE;
+  *device_points = f->d.out;
+  *n_out = f->n_out;
+  return PFT_OK;
+}
+
+extern "C" int pft_filter_get_output(pft_filter* f, pft_point_xyzrgba* host_out, size_t capacity, size_t* n_out) {
+  if (!f || !n_out) return PFT_ERR_INVALID_ARG;
+  if (!f->have_result) return PFT_ERR_STATE;
+  *n_out = f->n_out;
+  if (f->n_out > capacity) return PFT_ERR_CAPACITY;
+  if (f->n_out) {
+    if (!host_out) return PFT_ERR_INVALID_ARG;
+    FCHK(f, hipMemcpyAsync(host_out, f->d.out, f->n_out * sizeof(pft_point_xyzrgba), hipMemcpyDeviceToHost, f->stream));
+    FCHK(f, hipStreamSynchronize(f->stream));
+  }
+  return PFT_OK;
+}
+
+extern "C" int pft_filter_get_pass_indices(pft_filter* f, int32_t* host_idx, size_t capacity, size_t* n_pass) {
+  if (!f || !n_pass) return PFT_ERR_INVALID_ARG;
+  if (!f->have_result) return PFT_ERR_STATE;
+  *n_pass = f->n_pass;
+  if (f->n_pass > capacity) return PFT_ERR_CAPACITY;
+  if (f->n_pass) {
+    if (!host_idx) return PFT_ERR_INVALID_ARG;
+    FParams p = {};
+    p.n = (uint32_t)f->n_in;
+    hipLaunchKernelGGL(k_f_pass_indices, dim3(f->ntiles), dim3(F_THREADS), 0, f->stream, p, f->d);
+    FCHK(f, hipMemcpyAsync(host_idx, f->d.pass_idx, f->n_pass * sizeof(int32_t), hipMemcpyDeviceToHost, f->stream));
+    FCHK(f, hipStreamSynchronize(f->stream));
+  }
+  return PFT_OK;
+}
+
+extern "C" int pft_filter_last_ms(const pft_filter* f, double* ms) {
+  if (!f || !ms) return PFT_ERR_INVALID_ARG;
+  if (!f->have_result) return PFT_ERR_STATE;
+  *ms = f->last_ms;
+  return PFT_OK;
+}

@@ -235,6 +235,37 @@ def make_scene(N=50000, seed=SCENE_SEED, obj_pose=GT_POSE, mode="voxel", leaf=0.
     return make_points(xyz[sel].astype(np.float32), rgb[sel])
 
 
+def make_depth_frame(width=960, height=540, seed=SCENE_SEED, obj_pose=GT_POSE, dropout=0.03):
+    """Raw organised sensor frame as the reference receives it before filterPassThrough / gridSampleApprox
+    (auto_tracking.cpp:637, 683; Kinect2 'qhd' = 960x540, :775): width*height points in row-major order, rays
+    that hit nothing and a random `dropout` fraction of pixels are NaN (invalid depth), and a strip of far
+    background lies beyond the PassThrough limit z <= 10."""
+    rng = np.random.default_rng(seed)
+    boxes = _scene_boxes(obj_pose, rng)
+    far_rgb = np.tile(np.array([[90, 100, 120]]), (6, 1))
+    boxes[2] = _Box((1.0, 0.0, 2.5), (4.0, 4.0, 0.02), (0, 0, 0), boxes[2].face_rgb)  # wall leaves the left edge open
+    boxes.append(_Box((-3.0, 0.0, 12.0), (30.0, 9.0, 0.02), (0, 0, 0), far_rgb))  # visible through the gap, z = 12
+    u, v = np.meshgrid(np.arange(width), np.arange(height), indexing="xy")
+    fx = 0.82 * width
+    d = np.stack([(u.ravel() - (width - 1) / 2) / fx, (v.ravel() - (height - 1) / 2) / fx, np.ones(u.size)], 1)
+    best_t = np.full(len(d), np.inf)
+    best_rgb = np.zeros((len(d), 3), np.int32)
+    for b in boxes:
+        t, face = b.intersect(d)
+        closer = t < best_t
+        best_t = np.where(closer, t, best_t)
+        best_rgb[closer] = b.face_rgb[face[closer]]
+    ok = np.isfinite(best_t) & (rng.random(len(d)) >= dropout)
+    t = np.where(ok, best_t, 1.0)
+    xyz = d * t[:, None]
+    xyz = xyz * (1.0 + rng.normal(0, 0.0015, len(xyz)) / np.maximum(xyz[:, 2], 0.1))[:, None]
+    rgb = best_rgb + rng.integers(-8, 9, best_rgb.shape)
+    pts = make_points(xyz.astype(np.float32), rgb)
+    for k in ("x", "y", "z"):
+        pts[k][~ok] = np.nan
+    return pts
+
+
 def advance_pose(pose, frame):
     """ground-truth motion for multi-frame runs: +1 mm in x and +0.5 deg yaw per frame"""
     p = list(pose)

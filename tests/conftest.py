@@ -20,3 +20,17 @@ def orc():
 
     oracle.lib()
     return oracle
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_hip_first():
+    """PyTorch bundles its own HIP runtime; in a process that also uses torch on the GPU (test_gpu_dist,
+    bench.py) torch has to initialise it before libpft_hip.so does.  No-op without a GPU."""
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
+    yield

@@ -1,5 +1,5 @@
 """CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
-include/pft.h declares (no compute call is made here: there is no GPU in the build container)."""
+include/*.h declare (no compute call is made here: there is no GPU in the build container)."""
 import ctypes as C
 import os
 import re
@@ -20,9 +20,15 @@ def lib():
 
 
 def declared_functions():
-    src = open(os.path.join(ROOT, "include", "pft.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(pft_[a-z0-9_]+)\s*\(", src)))
+    names = set()
+    inc = os.path.join(ROOT, "include")
+    for h in sorted(os.listdir(inc)):
+        if not h.endswith(".h"):
+            continue
+        src = open(os.path.join(inc, h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(pft_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_every_declared_symbol_is_exported_and_bound(lib):
@@ -77,6 +83,16 @@ def test_host_helpers_match_oracle(lib, orc):
         assert back[0].tobytes() == orc.to_state(m).tobytes()
 
 
+def test_filter_config_defaults_are_the_reference_values(lib):
+    L = lib.load()
+    c = lib.FilterConfig()
+    L.pft_filter_default_config(C.byref(c))
+    # /root/reference/src/auto_tracking.cpp:536-547 (z in [0, 10]) and :563-575 (ApproximateVoxelGrid 0.01)
+    assert (c.pass_enable, c.pass_field, c.pass_min, c.pass_max, c.pass_negative) == (1, 2, 0.0, 10.0, 0)
+    assert c.voxel_mode == lib.VOXEL_APPROX and [round(v, 6) for v in c.leaf_size] == [0.01] * 3
+    assert c.approx_hist_size == 512 and c.max_points == 960 * 540
+
+
 def test_no_gpu_means_loud_failure(lib):
     """without a usable device pft_create refuses; there is no CPU fallback to fall into"""
     import torch
@@ -89,6 +105,9 @@ def test_no_gpu_means_loud_failure(lib):
     h = C.c_void_p()
     assert L.pft_create(C.byref(c), C.byref(h)) == 4  # PFT_ERR_NO_DEVICE
     assert not h.value
+    fc = lib.FilterConfig()
+    L.pft_filter_default_config(C.byref(fc))
+    assert L.pft_filter_create(C.byref(fc), C.byref(h)) == 4 and not h.value
     from pcl_tracking_amd import scene, tracker
     from pcl_tracking_amd._lib import PftError
 
