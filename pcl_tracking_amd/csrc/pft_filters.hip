@@ -51,11 +51,12 @@ struct FDev {
   pft_point_xyzrgba* out;
   uint32_t* key[2];
   uint32_t* val[2];
-  int4* cell;
+  uint16_t* key16;      // approximate grid: table entry of every point (0xFFFF = dropped), input order
+  float4* spt;          // approximate grid: {x, y, z, rgba bits} in table-entry order
+  uint32_t* trig_bits;  // approximate grid: bit i set = point i flushed the previous voxel of its table entry
+  uint32_t* word_pref;  // exclusive prefix of popcount(trig_bits[w])
   uint8_t* passf;
-  uint8_t* trig;
   uint8_t* head;
-  uint32_t* trig_pos;
   uint32_t* hist;
   uint32_t* tile_trig;
   uint32_t* tile_pass;
@@ -86,17 +87,12 @@ __device__ __forceinline__ bool f_passes(const FParams& p, float x, float y, flo
   return !(v >= p.pass_min && v <= p.pass_max);
 }
 
-// ---- stage 1: PassThrough decision, voxel / hash of every point, per-tile counts (and bounds) ----
+// ---- PassThrough alone and VoxelGrid, stage 1: PassThrough decision, per-tile counts (and bounds) ----
 __global__ __launch_bounds__(F_THREADS) void k_f_classify(FParams p, FDev d) {
   __shared__ uint32_t su[20];
   __shared__ float sf[6][20];
   const uint32_t t = blockIdx.x, tid = threadIdx.x;
-  if (t == 0)
-    for (uint32_t b = tid; b <= F_MAX_HIST; b += F_THREADS) d.bucket[b] = 0;
-  if (tid == 0) {
-    d.tile_trig[t] = 0;
-    d.tile_head[t] = 0;
-  }
+  if (tid == 0) d.tile_head[t] = 0;
   uint32_t cnt = 0;
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (int k = 0; k < 4; k++) {
@@ -105,15 +101,7 @@ __global__ __launch_bounds__(F_THREADS) void k_f_classify(FParams p, FDev d) {
     const float4 q = *reinterpret_cast<const float4*>(d.in + i);
     bool pass = f_passes(p, q.x, q.y, q.z);
     uint32_t kk = F_INVALID;
-    if (p.mode == PFT_VOXEL_APPROX) {
-      if (pass) {
-        const int ix = floor_to_int(q.x * p.inv[0]);
-        const int iy = floor_to_int(q.y * p.inv[1]);
-        const int iz = floor_to_int(q.z * p.inv[2]);
-        kk = ((uint32_t)ix * 7171u + (uint32_t)iy * 3079u + (uint32_t)iz * 4231u) & p.hist_mask;
-        d.cell[i] = make_int4(ix, iy, iz, (int)kk);
-      }
-    } else if (p.mode == PFT_VOXEL_EXACT) {
+    if (p.mode == PFT_VOXEL_EXACT) {
       pass = pass && finite3(q.x, q.y, q.z);  // the grid skips non-finite points (is_dense == false)
       if (pass) {
         mn[0] = fminf(mn[0], q.x); mn[1] = fminf(mn[1], q.y); mn[2] = fminf(mn[2], q.z);
@@ -125,7 +113,6 @@ __global__ __launch_bounds__(F_THREADS) void k_f_classify(FParams p, FDev d) {
     d.key[0][i] = kk;
     d.val[0][i] = i;
     d.passf[i] = pass ? 1 : 0;
-    d.trig[i] = 0;
     cnt += pass ? 1u : 0u;
   }
   uint32_t tot;
@@ -209,7 +196,8 @@ __global__ __launch_bounds__(64) void k_f_rs_hist(const uint32_t* __restrict__ k
   for (int b = lane; b < F_BINS; b += 64) hist[(size_t)b * ntiles + t] = h[b];
 }
 
-__global__ __launch_bounds__(F_THREADS) void k_f_rs_scan(uint32_t* __restrict__ hist, uint32_t ntiles) {
+// one workgroup per bin: exclusive scan of that bin's per-tile counts, bin total to hist[nbins*ntiles + b]
+__global__ __launch_bounds__(F_THREADS) void k_f_rs_scan(uint32_t* __restrict__ hist, uint32_t ntiles, uint32_t nbins) {
   __shared__ uint32_t scr[20];
   const uint32_t b = blockIdx.x, tid = threadIdx.x;
   uint32_t* row = hist + (size_t)b * ntiles;
@@ -222,7 +210,7 @@ __global__ __launch_bounds__(F_THREADS) void k_f_rs_scan(uint32_t* __restrict__ 
     if (t < ntiles) row[t] = carry + ex;
     carry += tot;
   }
-  if (tid == 0) hist[(size_t)F_BINS * ntiles + b] = carry;
+  if (tid == 0) hist[(size_t)nbins * ntiles + b] = carry;
 }
 
 __global__ __launch_bounds__(64) void k_f_rs_scatter(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
@@ -275,31 +263,6 @@ __global__ __launch_bounds__(64) void k_f_rs_scatter(const uint32_t* __restrict_
   }
 }
 
-// ---- ApproximateVoxelGrid: run heads and flush triggers in table-entry order ----
-__global__ __launch_bounds__(F_THREADS) void k_f_heads_approx(FParams p, FDev d, const uint32_t* __restrict__ skey,
-                                                              const uint32_t* __restrict__ sval) {
-  const uint32_t j = blockIdx.x * F_THREADS + threadIdx.x;
-  if (j >= p.n) return;
-  const uint32_t k = skey[j];
-  if (k == F_INVALID) {
-    d.head[j] = 0;
-    return;
-  }
-  const uint32_t v = sval[j];
-  bool first = true, head = true;
-  if (j > 0 && skey[j - 1] == k) {
-    first = false;
-    const int4 c = d.cell[v], q = d.cell[sval[j - 1]];
-    head = (c.x != q.x) || (c.y != q.y) || (c.z != q.z);
-  }
-  d.head[j] = head ? 1 : 0;
-  if (first) d.bucket[k] = 1;
-  if (head && !first) {  // v is the point whose arrival flushed the previous run of this entry
-    d.trig[v] = 1;
-    atomicAdd(&d.tile_trig[v / F_TILE], 1u);
-  }
-}
-
 // VoxelGrid: run heads in sorted order, per-tile head counts
 __global__ __launch_bounds__(F_THREADS) void k_f_heads_exact(FParams p, FDev d, const uint32_t* __restrict__ skey) {
   __shared__ uint32_t su[20];
@@ -337,11 +300,7 @@ __global__ __launch_bounds__(1024) void k_f_scan_small(FParams p, FDev d, uint32
   __shared__ uint32_t scr[20];
   const uint32_t n_pass = scan_array(d.tile_pass, ntiles, scr);
   uint32_t n_out = n_pass, n_trig = 0, n_present = 0;
-  if (p.mode == PFT_VOXEL_APPROX) {
-    n_trig = scan_array(d.tile_trig, ntiles, scr);
-    n_present = scan_array(d.bucket, p.hist_mask + 1u, scr);
-    n_out = n_trig + n_present;
-  } else if (p.mode == PFT_VOXEL_EXACT) {
+  if (p.mode == PFT_VOXEL_EXACT) {
     n_out = scan_array(d.tile_head, ntiles, scr);
     if (d.hdr->leaf_too_small) n_out = 0;
   }
@@ -356,60 +315,217 @@ __global__ __launch_bounds__(1024) void k_f_scan_small(FParams p, FDev d, uint32
   }
 }
 
-// exclusive rank of every trigger point in input order
-__global__ __launch_bounds__(F_THREADS) void k_f_trig_pos(FParams p, FDev d) {
-  __shared__ uint32_t su[20];
-  const uint32_t t = blockIdx.x, tid = threadIdx.x;
-  const uint32_t i0 = t * F_TILE + tid * 4;
-  uint32_t f[4], cnt = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    f[k] = (i0 + k < p.n) ? d.trig[i0 + k] : 0u;
-    cnt += f[k];
-  }
-  uint32_t tot;
-  uint32_t ex = d.tile_trig[t] + block_excl_scan<uint32_t>(cnt, su, &tot);
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    if (i0 + k < p.n) d.trig_pos[i0 + k] = ex;
-    ex += f[k];
-  }
-}
-
 __device__ __forceinline__ void store_point(pft_point_xyzrgba* o, float x, float y, float z, uint32_t rgba) {
   float4* q = reinterpret_cast<float4*>(o);
   q[0] = make_float4(x, y, z, 1.0f);
   q[1] = make_float4(__uint_as_float(rgba), 0.0f, 0.0f, 0.0f);
 }
 
-// one thread per run: the centroid in arrival order (flush()), written to its flush slot
-__global__ __launch_bounds__(F_THREADS) void k_f_emit_approx(FParams p, FDev d, const uint32_t* __restrict__ skey,
-                                                             const uint32_t* __restrict__ sval) {
+// ---------------------------------------------------------------------------------------------------
+// ApproximateVoxelGrid (+ PassThrough) in six launches:
+//   k_fa_classify  table entry of every point, per-tile histogram over the entries, zeroed trigger bits
+//   k_f_rs_scan    per entry: exclusive scan over the tiles, entry totals
+//   k_fa_scatter   stable counting sort by entry: {x, y, z, rgba} and the input index in entry order
+//   k_fa_heads     run heads; the first point of every later run of an entry is a flush trigger (bit set)
+//   k_fa_ranks     one workgroup: trigger ranks per 32-point word, ranks of the non-empty entries, counts
+//   k_fa_emit      one thread per run: centroid in arrival order, written to its flush slot
+__device__ __forceinline__ uint32_t cell_entry(const FParams& p, float x, float y, float z, int& ix, int& iy, int& iz) {
+  ix = floor_to_int(x * p.inv[0]);
+  iy = floor_to_int(y * p.inv[1]);
+  iz = floor_to_int(z * p.inv[2]);
+  return ((uint32_t)ix * 7171u + (uint32_t)iy * 3079u + (uint32_t)iz * 4231u) & p.hist_mask;
+}
+
+__global__ __launch_bounds__(F_THREADS) void k_fa_classify(FParams p, FDev d, uint32_t ntiles) {
+  __shared__ uint32_t h[F_MAX_HIST];
+  __shared__ uint32_t su[20];
+  const uint32_t t = blockIdx.x, tid = threadIdx.x, nb = p.hist_mask + 1u;
+  for (uint32_t b = tid; b < nb; b += F_THREADS) h[b] = 0;
+  if (tid < F_TILE / 32) d.trig_bits[t * (F_TILE / 32) + tid] = 0;
+  __syncthreads();
+  uint32_t cnt = 0;
+  for (int k = 0; k < 4; k++) {
+    const uint32_t i = t * F_TILE + k * F_THREADS + tid;
+    if (i >= p.n) break;
+    const float4 q = *reinterpret_cast<const float4*>(d.in + i);
+    const bool pass = f_passes(p, q.x, q.y, q.z);
+    uint32_t key = 0xFFFFu;
+    if (pass) {
+      int ix, iy, iz;
+      key = cell_entry(p, q.x, q.y, q.z, ix, iy, iz);
+      atomicAdd(&h[key], 1u);
+      cnt++;
+    }
+    d.key16[i] = (uint16_t)key;
+    d.passf[i] = pass ? 1 : 0;
+  }
+  __syncthreads();
+  for (uint32_t b = tid; b < nb; b += F_THREADS) d.hist[(size_t)b * ntiles + t] = h[b];
+  uint32_t tot;
+  block_excl_scan<uint32_t>(cnt, su, &tot);
+  if (tid == 0) d.tile_pass[t] = tot;
+}
+
+__global__ __launch_bounds__(64) void k_fa_scatter(FParams p, FDev d, uint32_t ntiles, int bits) {
+  __shared__ uint32_t cnt[F_MAX_HIST];
+  const uint32_t t = blockIdx.x, lane = threadIdx.x, nb = p.hist_mask + 1u;
+  const uint32_t* tot = d.hist + (size_t)nb * ntiles;
+  {  // entry bases = exclusive scan of the entry totals (consecutive entries per lane) + this tile's offset
+    const uint32_t per = nb >= 64u ? nb / 64u : 1u;
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < per; k++) {
+      const uint32_t b = lane * per + k;
+      if (b < nb) sum += tot[b];
+    }
+    const uint32_t inc = wave_incl_scan(sum);
+    uint32_t run = inc - sum;
+    for (uint32_t k = 0; k < per; k++) {
+      const uint32_t b = lane * per + k;
+      if (b < nb) {
+        cnt[b] = run + d.hist[(size_t)b * ntiles + t];
+        run += tot[b];
+      }
+    }
+    if (t == 0 && lane == 63) d.hdr->n_pass = inc;  // points that entered the grid
+  }
+  __syncthreads();
+  const uint32_t base = t * F_TILE;
+  for (uint32_t c = 0; c < F_TILE / 64; c++) {
+    const uint32_t i = base + c * 64 + lane;
+    uint32_t key = i < p.n ? (uint32_t)d.key16[i] : 0xFFFFu;
+    const bool valid = key != 0xFFFFu;
+    if (!valid) key = 0;
+    unsigned long long peers = __ballot(valid);
+    if (!valid) peers = ~peers;
+    for (int b = 0; b < bits; b++) {
+      const unsigned long long m = __ballot((key >> b) & 1u);
+      peers &= ((key >> b) & 1u) ? m : ~m;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t rank = __popcll(peers & lt);
+    const uint32_t dst0 = cnt[key];
+    __builtin_amdgcn_wave_barrier();
+    if (valid && rank == 0) cnt[key] = dst0 + (uint32_t)__popcll(peers);  // leader advances the running offset
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (valid) {
+      const float4* q = reinterpret_cast<const float4*>(d.in + i);
+      const float4 a = q[0];
+      d.spt[dst0 + rank] = make_float4(a.x, a.y, a.z, q[1].x);
+      d.val[0][dst0 + rank] = i;
+    }
+  }
+}
+
+__global__ __launch_bounds__(F_THREADS) void k_fa_heads(FParams p, FDev d) {
   const uint32_t j = blockIdx.x * F_THREADS + threadIdx.x;
-  if (j >= p.n || !d.head[j]) return;
-  const uint32_t b = skey[j];
+  const uint32_t nv = d.hdr->n_pass;
+  if (j > nv) return;
+  if (j == nv) {  // sentinel: ends the last run
+    d.head[j] = 2;
+    return;
+  }
+  const float4 a = d.spt[j];
+  int ax, ay, az;
+  const uint32_t ea = cell_entry(p, a.x, a.y, a.z, ax, ay, az);
+  uint32_t flag = 2;  // first run of its table entry
+  if (j > 0) {
+    const float4 b = d.spt[j - 1];
+    int bx, by, bz;
+    const uint32_t eb = cell_entry(p, b.x, b.y, b.z, bx, by, bz);
+    if (eb == ea) flag = (ax != bx || ay != by || az != bz) ? 1u : 0u;
+  }
+  d.head[j] = (uint8_t)flag;
+  if (flag == 1) {  // this point's arrival flushed the previous voxel of the entry
+    const uint32_t i = d.val[0][j];
+    atomicOr(&d.trig_bits[i >> 5], 1u << (i & 31u));
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_fa_ranks(FParams p, FDev d, uint32_t ntiles) {
+  __shared__ uint32_t scr[20];
+  const uint32_t tid = threadIdx.x, nb = p.hist_mask + 1u;
+  const uint32_t nwords = (p.n + 31u) / 32u;
+  // exclusive prefix of the trigger popcounts, 16 consecutive words per thread per round
+  uint32_t carry = 0;
+  for (uint32_t w0 = 0; w0 < nwords; w0 += 1024u * 16u) {
+    const uint32_t wb = w0 + tid * 16u;
+    uint32_t c[16], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      c[k] = (wb + k < nwords) ? __popc(d.trig_bits[wb + k]) : 0u;
+      sum += c[k];
+    }
+    uint32_t tot;
+    uint32_t ex = carry + block_excl_scan<uint32_t>(sum, scr, &tot);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      if (wb + k < nwords) d.word_pref[wb + k] = ex;
+      ex += c[k];
+    }
+    carry += tot;
+  }
+  const uint32_t n_trig = carry;
+  // ranks of the non-empty table entries (two consecutive entries per thread)
+  const uint32_t* tot = d.hist + (size_t)nb * ntiles;
+  const uint32_t b0 = tid * 2u;
+  const uint32_t f0 = (b0 < nb && tot[b0]) ? 1u : 0u, f1 = (b0 + 1u < nb && tot[b0 + 1u]) ? 1u : 0u;
+  uint32_t n_present;
+  const uint32_t ex = block_excl_scan<uint32_t>(f0 + f1, scr, &n_present);
+  if (b0 < nb) d.bucket[b0] = ex;
+  if (b0 + 1u < nb) d.bucket[b0 + 1u] = ex + f0;
+  if (tid == 0) {
+    d.hdr->n_trig = n_trig;
+    d.hdr->n_present = n_present;
+    d.hdr->n_out = n_trig + n_present;
+    d.hdr->leaf_too_small = 0;
+    d.host_stat[0] = d.hdr->n_pass;
+    d.host_stat[1] = n_trig + n_present;
+    d.host_stat[2] = 0;
+  }
+}
+
+__global__ __launch_bounds__(F_THREADS) void k_fa_emit(FParams p, FDev d) {
+  const uint32_t j = blockIdx.x * F_THREADS + threadIdx.x;
+  if (j >= d.hdr->n_pass || !d.head[j]) return;
   float sx = 0.0f, sy = 0.0f, sz = 0.0f, sr = 0.0f, sg = 0.0f, sb = 0.0f;
-  uint32_t e = j, count = 0;
-  do {
-    const float4* q = reinterpret_cast<const float4*>(d.in + sval[e]);
-    const float4 a = q[0];
-    const uint32_t rgba = __float_as_uint(q[1].x);
-    sx += a.x;
-    sy += a.y;
-    sz += a.z;
-    sr += (float)((rgba >> 16) & 255u);
-    sg += (float)((rgba >> 8) & 255u);
-    sb += (float)(rgba & 255u);
-    count++;
-    e++;
-  } while (e < p.n && skey[e] == b && !d.head[e]);
-  const float cnt = (float)count;
+  uint32_t e = j, hf;
+  float4 first;
+#define F_ACC(q)                                  \
+  do {                                            \
+    const uint32_t c_ = __float_as_uint((q).w);   \
+    sx += (q).x;                                  \
+    sy += (q).y;                                  \
+    sz += (q).z;                                  \
+    sr += (float)((c_ >> 16) & 255u);             \
+    sg += (float)((c_ >> 8) & 255u);              \
+    sb += (float)(c_ & 255u);                     \
+  } while (0)
+  for (;;) {  // four elements per round; loads past the run end are discarded (buffers are padded)
+    const float4 p0 = d.spt[e], p1 = d.spt[e + 1], p2 = d.spt[e + 2], p3 = d.spt[e + 3];
+    const uint32_t h1 = d.head[e + 1], h2 = d.head[e + 2], h3 = d.head[e + 3], h4 = d.head[e + 4];
+    if (e == j) first = p0;
+    F_ACC(p0);
+    if (h1) { e += 1; hf = h1; break; }
+    F_ACC(p1);
+    if (h2) { e += 2; hf = h2; break; }
+    F_ACC(p2);
+    if (h3) { e += 3; hf = h3; break; }
+    F_ACC(p3);
+    if (h4) { e += 4; hf = h4; break; }
+    e += 4;
+  }
+#undef F_ACC
+  const float cnt = (float)(e - j);
   const int rgb = ((int)(sr / cnt)) << 16 | ((int)(sg / cnt)) << 8 | ((int)(sb / cnt));
   uint32_t pos;
-  if (e < p.n && skey[e] == b)
-    pos = d.trig_pos[sval[e]];  // flushed when the next run of this entry arrived
-  else
-    pos = d.hdr->n_trig + d.bucket[b];  // still open at the end: flushed in table order
+  if (hf == 1) {  // flushed when the next voxel of this table entry arrived: rank of that trigger point
+    const uint32_t i = d.val[0][e];
+    pos = d.word_pref[i >> 5] + __popc(d.trig_bits[i >> 5] & ((1u << (i & 31u)) - 1u));
+  } else {  // still open at the end: flushed in table order
+    int ix, iy, iz;
+    pos = d.hdr->n_trig + d.bucket[cell_entry(p, first.x, first.y, first.z, ix, iy, iz)];
+  }
   store_point(d.out + pos, sx / cnt, sy / cnt, sz / cnt, (uint32_t)rgb);
 }
 
@@ -464,6 +580,11 @@ __global__ __launch_bounds__(F_THREADS) void k_f_gather(FParams p, FDev d, const
   o[1] = q[1];
 }
 
+__global__ __launch_bounds__(1024) void k_f_scan_tiles(FDev d, uint32_t ntiles) {
+  __shared__ uint32_t scr[20];
+  scan_array(d.tile_pass, ntiles, scr);
+}
+
 // indices kept by PassThrough, in input order (pcl::PassThrough::filter(std::vector<int>&))
 __global__ __launch_bounds__(F_THREADS) void k_f_pass_indices(FParams p, FDev d) {
   __shared__ uint32_t su[20];
@@ -506,6 +627,7 @@ struct pft_filter {
   size_t n_in = 0, n_pass = 0, n_out = 0;
   int leaf_too_small = 0;
   bool have_result = false;
+  bool tile_pass_scanned = false;
   double last_ms = 0.0;
 };
 
@@ -522,7 +644,7 @@ static void ffree(T*& p) {
 static void free_buffers(pft_filter* f) {
   FDev& d = f->d;
   ffree(f->d_in_own); ffree(d.out); ffree(d.key[0]); ffree(d.key[1]); ffree(d.val[0]); ffree(d.val[1]);
-  ffree(d.cell); ffree(d.passf); ffree(d.trig); ffree(d.head); ffree(d.trig_pos); ffree(d.hist);
+  ffree(d.key16); ffree(d.spt); ffree(d.trig_bits); ffree(d.word_pref); ffree(d.passf); ffree(d.head); ffree(d.hist);
   ffree(d.tile_trig); ffree(d.tile_pass); ffree(d.tile_head); ffree(d.bpart); ffree(d.pass_idx);
   f->cap = 0;
 }
@@ -541,12 +663,13 @@ static int ensure_capacity(pft_filter* f, size_t n) {
     FCHK(f, falloc(&d.key[k], cap));
     FCHK(f, falloc(&d.val[k], cap));
   }
-  FCHK(f, falloc(&d.cell, cap));
+  FCHK(f, falloc(&d.key16, cap));
+  FCHK(f, falloc(&d.spt, cap + 8));
+  FCHK(f, falloc(&d.trig_bits, cap / 32));
+  FCHK(f, falloc(&d.word_pref, cap / 32));
   FCHK(f, falloc(&d.passf, cap));
-  FCHK(f, falloc(&d.trig, cap + 4));
-  FCHK(f, falloc(&d.head, cap + 4));
-  FCHK(f, falloc(&d.trig_pos, cap));
-  FCHK(f, falloc(&d.hist, (size_t)F_BINS * nt + F_BINS));
+  FCHK(f, falloc(&d.head, cap + 8));
+  FCHK(f, falloc(&d.hist, (size_t)F_MAX_HIST * nt + F_MAX_HIST));
   FCHK(f, falloc(&d.tile_trig, nt));
   FCHK(f, falloc(&d.tile_pass, nt));
   FCHK(f, falloc(&d.tile_head, nt));
@@ -644,37 +767,45 @@ static int run_pipeline(pft_filter* f, const pft_point_xyzrgba* d_in, size_t n) 
   const uint32_t nblk = (uint32_t)((n + F_THREADS - 1) / F_THREADS);
   f->ntiles = ntiles;
   FCHK(f, hipEventRecord(f->ev0, s));
-  hipLaunchKernelGGL(k_f_classify, dim3(ntiles), dim3(F_THREADS), 0, s, p, d);
-  int npass = 1;
-  if (p.mode == PFT_VOXEL_APPROX) npass = 2;  // keys < 2048, invalid = 0xFFFFFFFF: bits 0..15 order them
-  if (p.mode == PFT_VOXEL_EXACT) {
-    npass = 4;
-    hipLaunchKernelGGL(k_f_bounds, dim3(1), dim3(F_THREADS), 0, s, p, d, ntiles);
-    hipLaunchKernelGGL(k_f_keys_exact, dim3(nblk), dim3(F_THREADS), 0, s, p, d);
-  }
-  int cur = 0;
-  for (int pass = 0; pass < npass; pass++) {
-    const int shift = 8 * pass;
-    hipLaunchKernelGGL(k_f_rs_hist, dim3(ntiles), dim3(64), 0, s, d.key[cur], p.n, shift, d.hist, ntiles);
-    hipLaunchKernelGGL(k_f_rs_scan, dim3(F_BINS), dim3(F_THREADS), 0, s, d.hist, ntiles);
-    hipLaunchKernelGGL(k_f_rs_scatter, dim3(ntiles), dim3(64), 0, s, d.key[cur], d.val[cur], d.key[1 - cur],
-                       d.val[1 - cur], p.n, shift, d.hist, ntiles);
-    cur = 1 - cur;
-  }
-  const uint32_t* skey = d.key[cur];
-  const uint32_t* sval = d.val[cur];
   if (p.mode == PFT_VOXEL_APPROX) {
-    hipLaunchKernelGGL(k_f_heads_approx, dim3(nblk), dim3(F_THREADS), 0, s, p, d, skey, sval);
-    hipLaunchKernelGGL(k_f_scan_small, dim3(1), dim3(1024), 0, s, p, d, ntiles);
-    hipLaunchKernelGGL(k_f_trig_pos, dim3(ntiles), dim3(F_THREADS), 0, s, p, d);
-    hipLaunchKernelGGL(k_f_emit_approx, dim3(nblk), dim3(F_THREADS), 0, s, p, d, skey, sval);
-  } else if (p.mode == PFT_VOXEL_EXACT) {
-    hipLaunchKernelGGL(k_f_heads_exact, dim3(ntiles), dim3(F_THREADS), 0, s, p, d, skey);
-    hipLaunchKernelGGL(k_f_scan_small, dim3(1), dim3(1024), 0, s, p, d, ntiles);
-    hipLaunchKernelGGL(k_f_emit_exact, dim3(ntiles), dim3(F_THREADS), 0, s, p, d, skey, sval);
+    const uint32_t nb = p.hist_mask + 1u;
+    int bits = 0;
+    while ((1u << bits) < nb) bits++;
+    hipLaunchKernelGGL(k_fa_classify, dim3(ntiles), dim3(F_THREADS), 0, s, p, d, ntiles);
+    hipLaunchKernelGGL(k_f_rs_scan, dim3(nb), dim3(F_THREADS), 0, s, d.hist, ntiles, nb);
+    hipLaunchKernelGGL(k_fa_scatter, dim3(ntiles), dim3(64), 0, s, p, d, ntiles, bits);
+    hipLaunchKernelGGL(k_fa_heads, dim3((uint32_t)((n + 1 + F_THREADS - 1) / F_THREADS)), dim3(F_THREADS), 0, s, p, d);
+    hipLaunchKernelGGL(k_fa_ranks, dim3(1), dim3(1024), 0, s, p, d, ntiles);
+    hipLaunchKernelGGL(k_fa_emit, dim3(nblk), dim3(F_THREADS), 0, s, p, d);
+    f->tile_pass_scanned = false;
   } else {
-    hipLaunchKernelGGL(k_f_scan_small, dim3(1), dim3(1024), 0, s, p, d, ntiles);
-    hipLaunchKernelGGL(k_f_gather, dim3(nblk), dim3(F_THREADS), 0, s, p, d, sval);
+    hipLaunchKernelGGL(k_f_classify, dim3(ntiles), dim3(F_THREADS), 0, s, p, d);
+    int npass = 1;
+    if (p.mode == PFT_VOXEL_EXACT) {
+      npass = 4;
+      hipLaunchKernelGGL(k_f_bounds, dim3(1), dim3(F_THREADS), 0, s, p, d, ntiles);
+      hipLaunchKernelGGL(k_f_keys_exact, dim3(nblk), dim3(F_THREADS), 0, s, p, d);
+    }
+    int cur = 0;
+    for (int pass = 0; pass < npass; pass++) {
+      const int shift = 8 * pass;
+      hipLaunchKernelGGL(k_f_rs_hist, dim3(ntiles), dim3(64), 0, s, d.key[cur], p.n, shift, d.hist, ntiles);
+      hipLaunchKernelGGL(k_f_rs_scan, dim3(F_BINS), dim3(F_THREADS), 0, s, d.hist, ntiles, (uint32_t)F_BINS);
+      hipLaunchKernelGGL(k_f_rs_scatter, dim3(ntiles), dim3(64), 0, s, d.key[cur], d.val[cur], d.key[1 - cur],
+                         d.val[1 - cur], p.n, shift, d.hist, ntiles);
+      cur = 1 - cur;
+    }
+    const uint32_t* skey = d.key[cur];
+    const uint32_t* sval = d.val[cur];
+    if (p.mode == PFT_VOXEL_EXACT) {
+      hipLaunchKernelGGL(k_f_heads_exact, dim3(ntiles), dim3(F_THREADS), 0, s, p, d, skey);
+      hipLaunchKernelGGL(k_f_scan_small, dim3(1), dim3(1024), 0, s, p, d, ntiles);
+      hipLaunchKernelGGL(k_f_emit_exact, dim3(ntiles), dim3(F_THREADS), 0, s, p, d, skey, sval);
+    } else {
+      hipLaunchKernelGGL(k_f_scan_small, dim3(1), dim3(1024), 0, s, p, d, ntiles);
+      hipLaunchKernelGGL(k_f_gather, dim3(nblk), dim3(F_THREADS), 0, s, p, d, sval);
+    }
+    f->tile_pass_scanned = true;
   }
   FCHK(f, hipEventRecord(f->ev1, s));
   FCHK(f, hipGetLastError());
@@ -764,6 +895,10 @@ extern "C" int pft_filter_get_pass_indices(pft_filter* f, int32_t* host_idx, siz
     if (!host_idx) return PFT_ERR_INVALID_ARG;
     FParams p = {};
     p.n = (uint32_t)f->n_in;
+    if (!f->tile_pass_scanned) {
+      hipLaunchKernelGGL(k_f_scan_tiles, dim3(1), dim3(1024), 0, f->stream, f->d, f->ntiles);
+      f->tile_pass_scanned = true;
+    }
     hipLaunchKernelGGL(k_f_pass_indices, dim3(f->ntiles), dim3(F_THREADS), 0, f->stream, p, f->d);
     FCHK(f, hipMemcpyAsync(host_idx, f->d.pass_idx, f->n_pass * sizeof(int32_t), hipMemcpyDeviceToHost, f->stream));
     FCHK(f, hipStreamSynchronize(f->stream));
