@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--organized", action="store_true", help="N = w*h depth image, no downsample (config 3)")
     ap.add_argument("--objects", type=int, default=1, help="independent trackers, one HIP stream each (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-frontend", action="store_true", help="skip the PassThrough + ApproximateVoxelGrid side measurement")
     ap.add_argument("--cpu-frames", type=int, default=3)
     return ap.parse_args()
 
@@ -59,6 +60,44 @@ def cpu_baseline(model, cloud, trans, P, threads):
         times.append(time.perf_counter() - t0)
         stages = tr.stage_times()
     return min(times), sorted(times)[len(times) // 2], stages
+
+
+def frontend_measurement(dev, with_cpu):
+    """SURVEY 8f row 1, reported beside the headline (never part of `value`): the reference's per-frame input
+    filters (auto_tracking.cpp:637 filterPassThrough, :683 gridSampleApprox) over a synthetic Kinect2 qhd frame
+    (960x540, :775) resident in HBM; CPU figure = the oracle's sequential restatement, one core."""
+    import numpy as np
+    import torch
+
+    from pcl_tracking_amd import filters, scene
+
+    frame = scene.make_depth_frame(960, 540)
+    d = torch.from_numpy(frame.view(np.uint8).reshape(-1).copy()).to(dev)
+    f = filters.make_reference_input_filter(device_id=dev.index or 0)
+    f.setInputCloudDevice(d.data_ptr(), len(frame), keepalive=d)
+    f.filterDevice()
+    ms, wall = [], []
+    for _ in range(50):
+        t0 = time.perf_counter()
+        f.filterDevice()
+        wall.append((time.perf_counter() - t0) * 1e3)
+        ms.append(f.lastMilliseconds())
+    n_pass, n_out = f.counts()
+    out = {"workload": "PassThrough z in [0,10] + ApproximateVoxelGrid(0.01, 512-entry table) on a 960x540 frame",
+           "points_in": len(frame), "points_pass": n_pass, "points_out": n_out,
+           "gpu_ms": float(np.median(ms)), "wall_ms_incl_sync": float(np.median(wall)),
+           "points_per_s": len(frame) / (float(np.median(ms)) * 1e-3)}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle
+
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            oracle.approx_voxel_grid(frame[oracle.pass_through(frame, "z", 0.0, 10.0)], 0.01, 512)
+            ts.append(time.perf_counter() - t0)
+        out["cpu_port_ms"] = min(ts) * 1e3
+    return out
 
 
 def main():
@@ -216,6 +255,8 @@ def main():
                     ("transform", "bbox_crop", "octree", "coherence", "normalize", "resample", "update"), stages)},
             }
             out["speedup_vs_cpu"] = pips / out["cpu_baseline"]["value"]
+        if world == 1 and not ARGS.no_frontend:
+            out["frontend"] = frontend_measurement(dev, not ARGS.no_cpu_baseline)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

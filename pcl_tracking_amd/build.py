@@ -63,7 +63,8 @@ def build_example(force=False, verbose=False):
     """the ROS-free C++ driver (host side in the reference's language) over the header-only mirror of the
     PCL classes and the C-ABI library"""
     lib = build()
-    deps = [EXAMPLE_SRC, os.path.join(_HERE, "include", "pft", "particle_filter_tracker.hpp"), lib]
+    deps = [EXAMPLE_SRC, os.path.join(_HERE, "include", "pft", "particle_filter_tracker.hpp"),
+            os.path.join(_HERE, "include", "pft", "filters.hpp"), lib]
     if not force and os.path.exists(EXAMPLE_BIN) and all(os.path.getmtime(d) <= os.path.getmtime(EXAMPLE_BIN) for d in deps):
         return EXAMPLE_BIN
     root = os.path.dirname(_HERE)

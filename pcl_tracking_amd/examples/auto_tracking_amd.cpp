@@ -3,11 +3,12 @@
 // re-centre, setReferenceCloud, setTrans) and the per-frame loop (:688-697: setInputCloud, compute), followed
 // by what drawResult() does with the pose (:309-316: toEigenMatrix(getResult())).
 //
-//   auto_tracking_amd <model.bin> <frame0.bin> [frame1.bin ...] [--particles N] [--seed S]
+//   auto_tracking_amd <model.bin> <frame0.bin> [frame1.bin ...] [--particles N] [--seed S] [--raw]
 //
 // *.bin = raw arrays of 32-byte pcl::PointXYZRGBA records (what a binary PCD body of x y z rgba holds).
-// The model is the segmented object cluster in the camera frame; frames are already voxel-downsampled
-// (gridSampleApprox, :683, is the first "next" row of SURVEY.md 8f and not part of this path).
+// The model is the segmented object cluster in the camera frame.  Without --raw the frames are already
+// filtered and downsampled; with --raw they are sensor frames and go through cloud_cb's front end first
+// (:637 filterPassThrough, :683 gridSampleApprox) on the device, the result staying in HBM for the tracker.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -16,6 +17,7 @@
 #include <string>
 #include <vector>
 
+#include "pft/filters.hpp"
 #include "pft/particle_filter_tracker.hpp"
 
 using namespace pft;
@@ -60,13 +62,15 @@ int main(int argc, char** argv) {
   std::vector<const char*> files;
   int particles = 400;
   uint64_t seed = 1;
+  bool raw = false;
   for (int i = 1; i < argc; i++) {
-    if (!std::strcmp(argv[i], "--particles") && i + 1 < argc) particles = std::atoi(argv[++i]);
+    if (!std::strcmp(argv[i], "--raw")) raw = true;
+    else if (!std::strcmp(argv[i], "--particles") && i + 1 < argc) particles = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--seed") && i + 1 < argc) seed = std::strtoull(argv[++i], nullptr, 10);
     else files.push_back(argv[i]);
   }
   if (files.size() < 2) {
-    std::fprintf(stderr, "usage: %s <model.bin> <frame.bin>... [--particles N] [--seed S]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s <model.bin> <frame.bin>... [--particles N] [--seed S] [--raw]\n", argv[0]);
     return 2;
   }
 
@@ -141,9 +145,20 @@ int main(int argc, char** argv) {
   tracker_->setMinIndices((int)ref_cloud->points.size() / 2);
 
   // ---- "track the object", auto_tracking.cpp:688-697, then drawResult :309-310 ----
+  InputFilter front_end;  // filterPassThrough (z in [0, 10]) + gridSampleApprox (0.01), fused on the device
   for (size_t f = 1; f < files.size(); f++) {
-    Cloud::Ptr cloud_pass_downsampled_ = load_bin(files[f]);
-    tracker_->setInputCloud(cloud_pass_downsampled_);
+    Cloud::Ptr cloud = load_bin(files[f]);
+    if (raw) {
+      const pft_point_xyzrgba* d_cloud = nullptr;
+      size_t n_down = 0;
+      front_end.setInputCloud(cloud);
+      front_end.filterDevice(&d_cloud, &n_down);
+      std::fprintf(stderr, "PointCloud before downsampled: %zu data points.\nPointCloud after downsampled: %zu data points.\n",
+                   front_end.passedPoints(), n_down);  // auto_tracking.cpp:682, 684
+      tracker_->setInputCloudDevice(d_cloud, n_down);
+    } else {
+      tracker_->setInputCloud(cloud);
+    }
     tracker_->compute();
     ParticleXYZRPY result = tracker_->getResult();
     Affine3f transformation = tracker_->toEigenMatrix(result);

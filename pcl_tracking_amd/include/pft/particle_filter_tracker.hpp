@@ -216,10 +216,25 @@ class ParticleFilterTracker {
     if (handle_ && ref_) check(pft_set_reference(handle_, ref_->points.data(), ref_->points.size()), "setReferenceCloud");
   }
   PointCloudInConstPtr getReferenceCloud() const { return ref_; }
-  void setInputCloud(const PointCloudInConstPtr& cloud) { input_ = cloud; }
+  void setInputCloud(const PointCloudInConstPtr& cloud) {
+    input_ = cloud;
+    dev_input_ = nullptr;
+  }
+  // a cloud already in HBM (n 32-byte points), e.g. the output of pft::InputFilter::filterDevice
+  void setInputCloudDevice(const pft_point_xyzrgba* device_points, size_t n) {
+    input_.reset();
+    dev_input_ = device_points;
+    dev_n_ = n;
+  }
 
   // ---- auto_tracking.cpp:693 ----
   void compute() {
+    if (dev_input_ && dev_n_) {
+      if (!ensure()) return;
+      if (check(pft_set_input_device(handle_, dev_input_, dev_n_), "setInputCloudDevice") != PFT_OK) return;
+      check(pft_compute(handle_), "compute");
+      return;
+    }
     if (!input_ || input_->points.empty()) {
       std::fprintf(stderr, "[pft::ParticleFilterTracker::compute] input cloud is empty or not set\n");
       return;  // PCL: PCL_ERROR + early return, no exception
@@ -290,6 +305,8 @@ class ParticleFilterTracker {
   pft_tracker* handle_;
   Affine3f trans_;
   PointCloudInConstPtr ref_, input_;
+  const pft_point_xyzrgba* dev_input_ = nullptr;
+  size_t dev_n_ = 0;
   CoherencePtr coherence_;
 };
 

@@ -76,7 +76,27 @@ def case_track(name, M, N, P, frames, seed):
     print(name, "final", res[-1][:3])
 
 
+def case_filters(name, w, h):
+    """the input front end on a small synthetic sensor frame"""
+    frame = scene.make_depth_frame(w, h)
+    leaf = 0.03  # the frame is small and sparse: a 3 cm leaf makes voxels hold several points
+    idx = orc.pass_through(frame, "z", 0.0, 10.0)
+    approx512 = orc.approx_voxel_grid(frame[idx], leaf, 512)
+    approx64 = orc.approx_voxel_grid(frame[idx], leaf, 64)
+    exact = orc.voxel_grid(frame[idx], leaf)
+
+    def pack(c):  # x, y, z, rgba: the other 16 bytes of a point are constant (data[3] = 1, padding 0)
+        return np.stack([c["x"].view(np.uint32), c["y"].view(np.uint32), c["z"].view(np.uint32), c["rgba"]], 1)
+
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), frame=pack(frame), pass_idx=idx, leaf=np.float32(leaf),
+                        approx512=pack(approx512), approx64=pack(approx64), exact=pack(exact))
+    print(name, len(frame), "->", len(idx), "->", len(approx512), len(approx64), len(exact))
+
+
 if __name__ == "__main__":
+    if "filters" in sys.argv[1:]:  # only the front-end fixture (leaves the tracker fixtures untouched)
+        case_filters("filters_small", 96, 54)
+        sys.exit(0)
     case_eval("eval_small", M=96, N=1500, P=24, seed=7)
     case_eval("eval_ragged", M=257, N=4001, P=33, seed=8)
     case_track("track_small", M=200, N=5000, P=200, frames=4, seed=12)

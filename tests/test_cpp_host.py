@@ -31,6 +31,11 @@ def test_cpp_mirror_uses_the_reference_call_names():
                  "ParticleFilterOMPTracker", "ApproxNearestPairPointCloudCoherence", "DistanceCoherence",
                  "HSVColorCoherence"):
         assert name in hdr, name
+    # the filter classes of cloud_cb's front end (auto_tracking.cpp:536-575)
+    fh = open(os.path.join(root, "pcl_tracking_amd", "include", "pft", "filters.hpp")).read()
+    for name in ("PassThrough", "ApproximateVoxelGrid", "VoxelGrid", "setFilterFieldName", "setFilterLimits",
+                 "setKeepOrganized", "setLeafSize", "setInputCloud", "filter"):
+        assert name in fh, name
 
 
 @pytest.mark.gpu
@@ -77,3 +82,33 @@ def test_cpp_driver_matches_python_binding(tmp_path):
         res = t.getResult()
         want = [float(res[k]) for k in ("x", "y", "z", "roll", "pitch", "yaw")]
         np.testing.assert_allclose(got[f], want, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_cpp_driver_raw_frames_go_through_the_device_front_end(tmp_path):
+    """--raw: sensor frame -> PassThrough + ApproximateVoxelGrid on the device -> tracker, all in HBM; the poses
+    equal those of the driver fed the frame the Python binding filtered"""
+    from pcl_tracking_amd import build, filters
+
+    exe = build.build_example()
+    model = scene.make_model(512)
+    cluster = model.copy()
+    off = np.array(scene.model_gt_pose()[:3], np.float32)
+    for k, name in enumerate(("x", "y", "z")):
+        cluster[name] = cluster[name] + off[k]
+    raw = scene.make_depth_frame(480, 270)
+    f = filters.make_reference_input_filter()
+    f.setInputCloud(raw)
+    down = f.filter()
+    cluster.tofile(tmp_path / "model.bin")
+    raw.tofile(tmp_path / "raw.bin")
+    down.tofile(tmp_path / "down.bin")
+    outs, errs = [], []
+    for args in ([str(tmp_path / "raw.bin"), "--raw"], [str(tmp_path / "down.bin")]):
+        r = subprocess.run([exe, str(tmp_path / "model.bin")] + args + ["--particles", "600", "--seed", "2"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append([line for line in r.stdout.splitlines() if line.startswith("frame")])
+        errs.append(r.stderr)
+    assert len(outs[0]) == 1 and outs[0] == outs[1]
+    assert "after downsampled: %d data points" % len(down) in errs[0]

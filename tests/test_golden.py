@@ -99,3 +99,46 @@ def test_gpu_matches_track_fixture():
         for i, k in enumerate(KEYS):
             j = i if i < 3 else i + 1  # x,y,z,w,roll,pitch,yaw,weight
             assert abs(float(r[k]) - float(want[j])) < 1e-4, (f, k)
+
+
+# ---- input front end: tests/golden/filters_small.npz ----
+def load_filters():
+    z = np.load(os.path.join(G, "filters_small.npz"))
+    d = {k: z[k] for k in z.files}
+    for k in ("frame", "approx512", "approx64", "exact"):
+        c = np.zeros(len(d[k]), scene.POINT_DTYPE)
+        c["x"], c["y"], c["z"] = (d[k][:, j].copy().view(np.float32) for j in range(3))
+        c["rgba"] = d[k][:, 3]
+        c["w"] = 1.0
+        d[k] = c
+    d["leaf"] = float(d["leaf"])
+    return d
+
+
+def test_oracle_reproduces_filter_fixture(orc):
+    d = load_filters()
+    idx = orc.pass_through(d["frame"], "z", 0.0, 10.0)
+    np.testing.assert_array_equal(idx, d["pass_idx"])
+    kept = d["frame"][idx]
+    assert orc.approx_voxel_grid(kept, d["leaf"], 512).tobytes() == d["approx512"].tobytes()
+    assert orc.approx_voxel_grid(kept, d["leaf"], 64).tobytes() == d["approx64"].tobytes()
+    assert orc.voxel_grid(kept, d["leaf"]).tobytes() == d["exact"].tobytes()
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_filter_fixture():
+    from pcl_tracking_amd import filters
+
+    d = load_filters()
+    f = filters.make_reference_input_filter()
+    f.setLeafSize(d["leaf"])
+    f.setInputCloud(d["frame"])
+    assert f.filter().tobytes() == d["approx512"].tobytes()
+    np.testing.assert_array_equal(f.passIndices(), d["pass_idx"])
+    f.setHistorySize(64)
+    f.setInputCloud(d["frame"])
+    assert f.filter().tobytes() == d["approx64"].tobytes()
+    g = filters.VoxelGrid()
+    g.setLeafSize(d["leaf"])
+    g.setInputCloud(d["frame"][d["pass_idx"]])
+    assert g.filter().tobytes() == d["exact"].tobytes()
