@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PFT_ABI_VERSION 1
+#define PFT_ABI_VERSION 2
 
 /* pcl::PointXYZRGBA (32 B, 16-aligned): x,y,z,1.0f | rgba (bytes b,g,r,a) | 12 B pad */
 typedef struct pft_point_xyzrgba {
@@ -79,6 +79,14 @@ typedef struct pft_config {
   int32_t rank, world_size;
   /* capacities (0 = grow on demand at set_reference / set_input) */
   uint32_t max_reference_points, max_input_points;
+  /* KLDAdaptiveParticleFilterOMPTracker, the tracker auto_tracking.cpp runs unless use_fixed is set (:207-222, :821):
+   * particle_num is then only the initial count; every resample draws until the KL bound is met */
+  int32_t kld_adaptive;          /* 0: ParticleFilterOMPTracker (:203-204)   1: KLD-adaptive (:207-208) */
+  int32_t maximum_particle_num;  /* setMaximumParticleNum :209   500 */
+  double kld_delta;              /* setDelta              :210   0.99 */
+  double kld_epsilon;            /* setEpsilon            :211   0.2 */
+  double kld_bin_size[6];        /* setBinSize            :212-219  0.1 each */
+  double motion_ratio;           /* ParticleFilterTracker ctor default 0.25 (used by the KLD resample only) */
 } pft_config;
 
 typedef struct pft_tracker pft_tracker;
@@ -161,6 +169,14 @@ int pft_debug_resample(pft_tracker* t, const pft_particle* old, size_t n_total, 
                        const pft_particle* rep, uint32_t epoch, uint32_t id_offset, size_t n_local,
                        pft_particle* out);
 int pft_debug_pose_to_matrix(pft_tracker* t, const pft_particle* p, size_t n, float* m12);
+/* KLD resample alone: n_old particles + their explicit alias table (a, q) + motion -> the new particle set
+ * (capacity maximum_particle_num), their 6-D bins, the new count and the number of distinct bins */
+int pft_debug_kld_resample(pft_tracker* t, const pft_particle* old, size_t n_old, const int32_t* a, const double* q,
+                           const pft_particle* motion, uint32_t epoch, pft_particle* out, int32_t* bins6,
+                           uint32_t* n_out, uint32_t* k_out);
+/* host-side KLDAdaptiveParticleFilterTracker::normalQuantile / calcKLBound (what the resample kernel is given) */
+double pft_kld_normal_quantile(double u);
+double pft_kld_bound(int k, double delta, double epsilon);
 
 /* ---- per-kernel HIP-event timing on the handle's stream ---- */
 enum {

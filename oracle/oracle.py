@@ -31,6 +31,8 @@ class Config(C.Structure):
         ("h_weight", C.c_double), ("s_weight", C.c_double), ("v_weight", C.c_double),
         ("hsv_pcl180_argorder", C.c_int32), ("threads", C.c_int32), ("emulate_pcl_alloc", C.c_int32),
         ("seed", C.c_uint64),
+        ("kld_adaptive", C.c_int32), ("kld_max_particles", C.c_int32), ("kld_delta", C.c_double),
+        ("kld_epsilon", C.c_double), ("kld_bin_size", C.c_double * 6), ("motion_ratio", C.c_double),
     ]
 
 
@@ -103,6 +105,12 @@ def lib():
     L.orc_tracker_set_matrix_override.argtypes = [vp, vp]
     L.orc_tracker_set_bbox_override.argtypes = [vp, vp]
     L.orc_tracker_set_bbox_only.argtypes = [vp, C.c_int]
+    L.orc_kld_normal_quantile.argtypes = [f64]
+    L.orc_kld_normal_quantile.restype = f64
+    L.orc_kld_bound.argtypes = [C.c_int, f64, f64]
+    L.orc_kld_bound.restype = f64
+    L.orc_kld_resample.argtypes = [P(Config), vp, sz, vp, vp, vp, u32, vp, vp, P(i32)]
+    L.orc_kld_resample.restype = sz
     L.orc_pass_through.argtypes = [vp, sz, C.c_int, f32, f32, C.c_int, vp]
     L.orc_pass_through.restype = sz
     L.orc_approx_voxel_grid.argtypes = [vp, sz, vp, u32, vp]
@@ -121,7 +129,7 @@ def default_config(**kw):
     c = Config()
     lib().orc_config_default(C.byref(c))
     for k, v in kw.items():
-        if k in ("step_cov", "init_cov", "init_mean"):
+        if k in ("step_cov", "init_cov", "init_mean", "kld_bin_size"):
             for i in range(6):
                 getattr(c, k)[i] = float(v[i])
         else:
@@ -265,6 +273,28 @@ def resample(cfg, old, a, q, rep, epoch, id_offset=0, n_local=None):
     lib().orc_resample(C.byref(cfg), _ptr(old), len(old), _ptr(a), _ptr(q), _ptr(rep), epoch, id_offset, n_local,
                        _ptr(out))
     return out
+
+
+def kld_normal_quantile(u):
+    return lib().orc_kld_normal_quantile(u)
+
+
+def kld_bound(k, delta=0.99, epsilon=0.2):
+    return lib().orc_kld_bound(k, delta, epsilon)
+
+
+def kld_resample(cfg, old, a, q, motion, epoch):
+    """KLDAdaptiveParticleFilterTracker::resample -> (new particles, bins (n,6), distinct-bin count k)"""
+    old = np.ascontiguousarray(old)
+    out = np.zeros(cfg.kld_max_particles, PARTICLE_DTYPE)
+    bins = np.zeros((cfg.kld_max_particles, 6), np.int32)
+    k = C.c_int32()
+    a = np.ascontiguousarray(a, np.int32)
+    q = np.ascontiguousarray(q, np.float64)
+    motion = np.ascontiguousarray(motion)
+    n = lib().orc_kld_resample(C.byref(cfg), _ptr(old), len(old), _ptr(a), _ptr(q), _ptr(motion), epoch,
+                               _ptr(out), _ptr(bins), C.byref(k))
+    return out[:n].copy(), bins[:n].copy(), k.value
 
 
 def pass_through(pts, field="z", lo=0.0, hi=10.0, negative=False):

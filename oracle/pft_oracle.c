@@ -49,6 +49,12 @@ void orc_config_default(orc_config_t* c) {
   c->threads = 16; /* :845 */
   c->emulate_pcl_alloc = 1;
   c->seed = 1;
+  c->kld_adaptive = 0;
+  c->kld_max_particles = 500; /* :209 */
+  c->kld_delta = 0.99;        /* :210 */
+  c->kld_epsilon = 0.2;       /* :211 */
+  for (int k = 0; k < 6; k++) c->kld_bin_size[k] = 0.1; /* :212-219 */
+  c->motion_ratio = 0.25;
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -620,6 +626,87 @@ void orc_resample(const orc_config_t* c, const orc_particle_t* old, size_t n_tot
 }
 
 /* ------------------------------------------------------------------------------------------- */
+/* KLD-adaptive resampling (PCL 1.8.0 tracking/kld_adaptive_particle_filter.h, impl/...hpp)      */
+/* ------------------------------------------------------------------------------------------- */
+double orc_kld_normal_quantile(double u) {
+  /* CACM Algorithm 209 "Gauss" coefficients, as upstream (the last-but-one b coefficient is quoted from the
+   * algorithm, 5.35310849e-4; an upstream typo there would move z in the 10th digit only) */
+  static const double a[9] = {1.24818987e-4, -1.075204047e-3, 5.198775019e-3, -0.019198292004, 0.059054035642,
+                              -0.151968751364, 0.319152932694, -0.5319230073, 0.797884560593};
+  static const double b[15] = {-4.5255659e-5, 1.5252929e-4, -1.9538132e-5, -6.76904986e-4, 1.390604284e-3,
+                               -7.9462082e-4, -2.034254874e-3, 6.549791214e-3, -0.010557625006, 0.011630447319,
+                               -9.279453341e-3, 5.353579108e-3, -2.141268741e-3, 5.35310849e-4, 9.99936657524e-1};
+  double w, y, z;
+  if (u == 0.) return 0.5;
+  y = u / 2.0;
+  if (y < -6.) return 0.0;
+  if (y > 6.) return 1.0;
+  if (y < 0.) y = -y;
+  if (y < 1.) {
+    w = y * y;
+    z = a[0];
+    for (int i = 1; i < 9; i++) z = z * w + a[i];
+    z *= (y * 2.0);
+  } else {
+    y -= 2.0;
+    z = b[0];
+    for (int i = 1; i < 15; i++) z = z * y + b[i];
+  }
+  if (u < 0.0) return (1. - z) / 2.0;
+  return (1. + z) / 2.0;
+}
+
+double orc_kld_bound(int k, double delta, double epsilon) {
+  double z = orc_kld_normal_quantile(delta);
+  double chi = 1.0 - 2.0 / (9.0 * (k - 1)) + sqrt(2.0 / (9.0 * (k - 1))) * z;
+  return ((k - 1.0) / 2.0 / epsilon) * chi * chi * chi;
+}
+
+/* do { j = sampleWithReplacement(a, q); x = particles[j]; x.sample(0, step_cov);
+ *      if (rand()/RAND_MAX < motion_ratio) x = x + motion;  S.push_back(x);
+ *      bin[i] = (int)(x[i] / bin_size[i]);  if (insertIntoBins(bin, B)) ++k;  ++n;
+ * } while (n < max && (k < 2 || n < calcKLBound(k)));
+ * RNG: sample n draws from the Philox stream of "particle id" n with purpose 2: slot 0 the alias draw, slots
+ * 1-3 the step noise, slot 4 the motion coin (upstream: boost mt19937 + C rand(), unseedable). */
+size_t orc_kld_resample(const orc_config_t* c, const orc_particle_t* old, size_t n_old, const int32_t* a,
+                        const double* q, const orc_particle_t* motion, uint32_t epoch, orc_particle_t* out,
+                        int32_t* bins_out, int32_t* k_out) {
+  static const double zero_mean[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned maxn = (unsigned)c->kld_max_particles;
+  int32_t* B = (int32_t*)malloc(sizeof(int32_t) * 6 * (maxn ? maxn : 1));
+  unsigned k = 0, n = 0;
+  float bs[6];
+  for (int i = 0; i < 6; i++) bs[i] = (float)c->kld_bin_size[i];
+  do {
+    double rU = orc_rng_uniform(c->seed, n, 0, epoch, 2) * (double)n_old;
+    int kk = (int)rU;
+    rU -= kk;
+    int j_n = (rU < q[kk]) ? kk : a[kk];
+    orc_particle_t x = old[j_n];
+    particle_sample(&x, zero_mean, c->step_cov, c->seed, n, epoch, 2);
+    if (orc_rng_uniform(c->seed, n, 4, epoch, 2) < c->motion_ratio) { /* StateT operator+: the six pose floats */
+      x.x = x.x + motion->x; x.y = x.y + motion->y; x.z = x.z + motion->z;
+      x.roll = x.roll + motion->roll; x.pitch = x.pitch + motion->pitch; x.yaw = x.yaw + motion->yaw;
+    }
+    out[n] = x;
+    const float v[6] = {x.x, x.y, x.z, x.roll, x.pitch, x.yaw};
+    int32_t bin[6];
+    for (int i = 0; i < 6; i++) bin[i] = (int32_t)(v[i] / bs[i]);
+    if (bins_out) memcpy(bins_out + 6 * n, bin, sizeof(bin));
+    int found = 0;
+    for (unsigned m = 0; m < k && !found; m++) found = memcmp(B + 6 * m, bin, sizeof(bin)) == 0;
+    if (!found) {
+      memcpy(B + 6 * k, bin, sizeof(bin));
+      ++k;
+    }
+    ++n;
+  } while (n < maxn && (k < 2 || (double)n < orc_kld_bound((int)k, c->kld_delta, c->kld_epsilon)));
+  free(B);
+  if (k_out) *k_out = (int32_t)k;
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------------- */
 /* The tracker: ParticleFilterOMPTracker (PCL 1.8.0 tracking/impl/particle_filter_omp.hpp,       */
 /* particle_filter.hpp, tracker.hpp)                                                             */
 /* ------------------------------------------------------------------------------------------- */
@@ -862,8 +949,12 @@ static void tracker_resample(orc_tracker_t* t) {
   float* w = (float*)malloc(sizeof(float) * P);
   for (size_t i = 0; i < P; i++) w[i] = t->particles[i].weight;
   orc_gen_alias_table(w, P, a, q);
-  orc_particle_t* np = (orc_particle_t*)malloc(sizeof(orc_particle_t) * P);
-  orc_resample(&t->cfg, t->particles, P, a, q, &t->rep, t->resample_epoch, 0, P, np);
+  const size_t cap = t->cfg.kld_adaptive ? (size_t)t->cfg.kld_max_particles : P;
+  orc_particle_t* np = (orc_particle_t*)malloc(sizeof(orc_particle_t) * (cap ? cap : 1));
+  if (t->cfg.kld_adaptive) /* particles_ = S; particle_num_ = S.size() */
+    t->P = orc_kld_resample(&t->cfg, t->particles, P, a, q, &t->motion, t->resample_epoch, np, NULL, NULL);
+  else
+    orc_resample(&t->cfg, t->particles, P, a, q, &t->rep, t->resample_epoch, 0, P, np);
   t->resample_epoch++;
   free(t->particles);
   t->particles = np;

@@ -56,6 +56,13 @@ typedef struct {
   int32_t threads;           /* :845 16 OpenMP threads; <=0 -> omp default */
   int32_t emulate_pcl_alloc; /* 1: per-query index-vector malloc as OctreePointCloudSearch does */
   uint64_t seed;             /* counter-based RNG key (PCL itself is time(0)-seeded, unobservable) */
+  /* KLDAdaptiveParticleFilterOMPTracker, the reference's runtime default (use_fixed == false, :821; :207-222) */
+  int32_t kld_adaptive;      /* 0: ParticleFilterOMPTracker (:203-204)   1: KLD-adaptive variant (:207-208) */
+  int32_t kld_max_particles; /* :209  setMaximumParticleNum(500) */
+  double kld_delta;          /* :210  0.99 */
+  double kld_epsilon;        /* :211  0.2 */
+  double kld_bin_size[6];    /* :212-219  0.1 each (stored as the float members of a ParticleXYZRPY upstream) */
+  double motion_ratio;       /* PCL particle_filter.h ctor: 0.25 */
 } orc_config_t;
 
 void orc_config_default(orc_config_t* c);
@@ -146,6 +153,16 @@ size_t orc_tracker_eval_weights(orc_tracker_t* t, const orc_particle_t* particle
 /* per-stage wall time of the last compute(), seconds: [0]=transform [1]=bbox+crop [2]=octree build
  * [3]=coherence [4]=normalize [5]=resample [6]=update */
 void orc_tracker_stage_times(const orc_tracker_t* t, double s[7]);
+
+/* KLDAdaptiveParticleFilterTracker::normalQuantile (kld_adaptive_particle_filter.h): despite its name the
+ * polynomial normal CDF of CACM Algorithm 209; and calcKLBound(k) with z = normalQuantile(delta) */
+double orc_kld_normal_quantile(double u);
+double orc_kld_bound(int k, double delta, double epsilon);
+/* KLDAdaptiveParticleFilterTracker::resample (impl/kld_adaptive_particle_filter.hpp): draws until the KL bound
+ * is met; out has room for cfg->kld_max_particles; returns the new particle count */
+size_t orc_kld_resample(const orc_config_t* c, const orc_particle_t* old, size_t n_old, const int32_t* a,
+                        const double* q, const orc_particle_t* motion, uint32_t epoch, orc_particle_t* out,
+                        int32_t* bins_out /* 6 per particle, may be NULL */, int32_t* k_out /* distinct bins */);
 
 /* ---- input filters in front of the tracker (pft_oracle_filters.c) ---- */
 /* PassThrough with a field name (0 = x, 1 = y, 2 = z), inclusive limits, keep_organized = false; returns #kept */

@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libpft_hip.so")
 
-PFT_ABI_VERSION = 1
+PFT_ABI_VERSION = 2
 K_RESAMPLE, K_AABB, K_CROP, K_OCTREE, K_LIKELIHOOD, K_POPULATION, K_PACK, K_COUNT = range(8)
 
 STATUS = {0: "ok", 1: "invalid argument", 2: "no input cloud", 3: "no reference cloud", 4: "no usable HIP device",
@@ -32,6 +32,8 @@ class Config(C.Structure):
         ("hsv_pcl180_argorder", C.c_int32), ("use_normal", C.c_int32), ("seed", C.c_uint64),
         ("rank", C.c_int32), ("world_size", C.c_int32),
         ("max_reference_points", C.c_uint32), ("max_input_points", C.c_uint32),
+        ("kld_adaptive", C.c_int32), ("maximum_particle_num", C.c_int32), ("kld_delta", C.c_double),
+        ("kld_epsilon", C.c_double), ("kld_bin_size", C.c_double * 6), ("motion_ratio", C.c_double),
     ]
 
 
@@ -91,6 +93,9 @@ SYMBOLS = [
     ("pft_debug_init_particles", C.c_int, [_vp, _vp, _u32, _sz, _vp]),
     ("pft_debug_resample", C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp, _u32, _u32, _sz, _vp]),
     ("pft_debug_pose_to_matrix", C.c_int, [_vp, _vp, _sz, _vp]),
+    ("pft_debug_kld_resample", C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp, _u32, _vp, _vp, _P(_u32), _P(_u32)]),
+    ("pft_kld_normal_quantile", _f64, [_f64]),
+    ("pft_kld_bound", _f64, [C.c_int, _f64, _f64]),
     ("pft_profile_enable", C.c_int, [_vp, C.c_int]),
     ("pft_profile_get", C.c_int, [_vp, C.c_int, _P(_f64), _P(_u64)]),
     ("pft_profile_reset", C.c_int, [_vp]),

@@ -66,6 +66,9 @@ struct pft_tracker {
   int32_t* d_alias_list = nullptr;
   double* d_alias_pref = nullptr;
   double* d_pop_part = nullptr;
+  uint32_t* d_kld_table = nullptr;
+  int32_t* d_kld_bins = nullptr;
+  uint32_t Pcap = 0;  // particle capacity of the buffers (== P_total unless KLD-adaptive)
   uint32_t* d_alias_pos = nullptr;
   PftHeader* d_hdr = nullptr;
   int32_t* d_nn_idx = nullptr;
@@ -141,6 +144,46 @@ extern "C" void pft_config_default(pft_config* c) {
   c->seed = 1;
   c->rank = 0;
   c->world_size = 1;
+  c->kld_adaptive = 0;            // the north_star path is the fixed tracker; auto_tracking.cpp:207-222 for the KLD one
+  c->maximum_particle_num = 500;  // :209
+  c->kld_delta = 0.99;            // :210
+  c->kld_epsilon = 0.2;           // :211
+  for (int k = 0; k < 6; k++) c->kld_bin_size[k] = 0.1;  // :212-219
+  c->motion_ratio = 0.25;
+}
+
+// KLDAdaptiveParticleFilterTracker::normalQuantile (kld_adaptive_particle_filter.h): despite its name the polynomial
+// normal CDF of CACM Algorithm 209; host-side double arithmetic, handed to the resample kernel as a constant
+extern "C" double pft_kld_normal_quantile(double u) {
+  static const double a[9] = {1.24818987e-4, -1.075204047e-3, 5.198775019e-3, -0.019198292004, 0.059054035642,
+                              -0.151968751364, 0.319152932694, -0.5319230073, 0.797884560593};
+  static const double b[15] = {-4.5255659e-5, 1.5252929e-4, -1.9538132e-5, -6.76904986e-4, 1.390604284e-3,
+                               -7.9462082e-4, -2.034254874e-3, 6.549791214e-3, -0.010557625006, 0.011630447319,
+                               -9.279453341e-3, 5.353579108e-3, -2.141268741e-3, 5.35310849e-4, 9.99936657524e-1};
+  double w, y, z;
+  if (u == 0.) return 0.5;
+  y = u / 2.0;
+  if (y < -6.) return 0.0;
+  if (y > 6.) return 1.0;
+  if (y < 0.) y = -y;
+  if (y < 1.) {
+    w = y * y;
+    z = a[0];
+    for (int i = 1; i < 9; i++) z = z * w + a[i];
+    z *= (y * 2.0);
+  } else {
+    y -= 2.0;
+    z = b[0];
+    for (int i = 1; i < 15; i++) z = z * y + b[i];
+  }
+  if (u < 0.0) return (1. - z) / 2.0;
+  return (1. + z) / 2.0;
+}
+
+extern "C" double pft_kld_bound(int k, double delta, double epsilon) {
+  const double z = pft_kld_normal_quantile(delta);
+  const double chi = 1.0 - 2.0 / (9.0 * (k - 1)) + sqrt(2.0 / (9.0 * (k - 1))) * z;
+  return ((k - 1.0) / 2.0 / epsilon) * chi * chi * chi;
 }
 
 // ---- host-side A1 / A0 helpers (toEigenMatrix / toState), float like PCL ----
@@ -268,6 +311,9 @@ static void sync_dev(pft_tracker* t) {
   d.alias_list = t->d_alias_list;
   d.alias_pref = t->d_alias_pref;
   d.pop_part = t->d_pop_part;
+  d.p_active = t->prm.kld ? &t->d_hdr->p_active : nullptr;
+  d.kld_table = t->d_kld_table;
+  d.kld_bins = t->d_kld_bins;
   d.alias_pos = t->d_alias_pos;
   d.hdr = t->d_hdr;
   d.nn_idx = t->d_nn_idx;
@@ -320,6 +366,13 @@ extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
       cfg->particle_num % cfg->world_size != 0 || !(cfg->octree_resolution > 0))
     return PFT_ERR_INVALID_ARG;
   if (cfg->particle_num > PFT_MAX_PARTICLES) return PFT_ERR_CAPACITY;
+  if (cfg->kld_adaptive) {
+    if (cfg->world_size != 1 || cfg->maximum_particle_num <= 0 || !(cfg->kld_epsilon > 0)) return PFT_ERR_INVALID_ARG;
+    for (int k = 0; k < 6; k++)
+      if (!(cfg->kld_bin_size[k] > 0)) return PFT_ERR_INVALID_ARG;
+    // the population stage of a KLD tracker runs in the single-workgroup kernel
+    if (cfg->maximum_particle_num >= PFT_POPM_MIN || cfg->particle_num >= PFT_POPM_MIN) return PFT_ERR_CAPACITY;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device_id >= ndev) return PFT_ERR_NO_DEVICE;
   if (hipSetDevice(cfg->device_id) != hipSuccess) return PFT_ERR_NO_DEVICE;
@@ -363,8 +416,16 @@ extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
   p.id_offset = p.P_local * (uint32_t)cfg->rank;
   p.M = 0;
   p.nchunk = 1;
+  p.kld = cfg->kld_adaptive ? 1u : 0u;
+  p.kld_max = (uint32_t)cfg->maximum_particle_num;
+  p.kld_z = pft_kld_normal_quantile(cfg->kld_delta);
+  p.kld_eps = cfg->kld_epsilon;
+  for (int k = 0; k < 6; k++) p.kld_bin[k] = (float)cfg->kld_bin_size[k];
+  p.motion_ratio = cfg->motion_ratio;
+  // capacity in particles: the KLD variant grows / shrinks between particle_num and maximum_particle_num
+  t->Pcap = p.kld && p.kld_max > p.P_total ? p.kld_max : p.P_total;
 
-  const size_t Pl = p.P_local, Pt = p.P_total;
+  const size_t Pl = p.kld ? t->Pcap : p.P_local, Pt = t->Pcap;
   hipError_t e = hipSuccess;
   auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
   A(dalloc(&t->d_part[0], Pt));  // sized P_total so part_all can alias a shard buffer when world_size == 1
@@ -378,6 +439,10 @@ extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
   A(dalloc(&t->d_alias_pref, 2 * Pt));
   A(dalloc(&t->d_pop_part, (size_t)PFT_POPM_MAX_WGS * 16));
   A(dalloc(&t->d_alias_pos, Pt));
+  if (p.kld) {
+    A(dalloc(&t->d_kld_table, (size_t)6 * p.kld_max + 128));
+    A(dalloc(&t->d_kld_bins, (size_t)6 * p.kld_max));
+  }
   A(hipHostMalloc(reinterpret_cast<void**>(&t->h_stat), 4 * sizeof(uint32_t), hipHostMallocMapped));
   if (t->h_stat) t->h_stat[0] = t->h_stat[1] = 0;
   {
@@ -424,7 +489,7 @@ extern "C" void pft_destroy(pft_tracker* t) {
   dfree(t->d_pt_key64); dfree(t->sort.keys[0]); dfree(t->sort.keys[1]); dfree(t->sort.vals[0]); dfree(t->sort.vals[1]);
   dfree(t->sort.hist); dfree(t->sort.tile_cnt); dfree(t->sort.tile_box); if (t->h_stat) hipHostFree(t->h_stat);
   dfree(t->d_partial); dfree(t->d_alias_list); dfree(t->d_alias_pos);
-  dfree(t->d_alias_pref); dfree(t->d_pop_part); dfree(t->d_hdr); dfree(t->d_nn_idx); dfree(t->d_nn_d2); dfree(t->d_dbg_part);
+  dfree(t->d_alias_pref); dfree(t->d_pop_part); dfree(t->d_kld_table); dfree(t->d_kld_bins); dfree(t->d_hdr); dfree(t->d_nn_idx); dfree(t->d_nn_d2); dfree(t->d_dbg_part);
   dfree(t->d_dbg_hdr); dfree(t->d_dbg_f);
   if (t->own_stream && t->stream) hipStreamDestroy(t->stream);
   delete t;
@@ -455,7 +520,7 @@ extern "C" int pft_set_reference(pft_tracker* t, const pft_point_xyzrgba* pts, s
   t->prm.nchunk = (uint32_t)((n + PFT_REF_CHUNK - 1) / PFT_REF_CHUNK);
   if (t->prm.nchunk == 0) t->prm.nchunk = 1;
   dfree(t->d_partial);
-  HIPCHK(t, dalloc(&t->d_partial, (size_t)t->prm.P_local * t->prm.nchunk));
+  HIPCHK(t, dalloc(&t->d_partial, (size_t)(t->prm.kld ? t->Pcap : t->prm.P_local) * t->prm.nchunk));
   if (n) {
     // The reference cloud is stored in Morton (Z-curve) order: the 64 lanes of a wave then query
     // neighbouring space, so their octree paths and leaf records share LDS words and cache lines.  Every
@@ -561,7 +626,10 @@ static void stage_resample(pft_tracker* t) {
   pft_particle* out = t->d_part[1 - t->cur];
   {
     ProfScope ps(t, PFT_K_RESAMPLE);
-    pftk_resample(t->stream, t->prm, t->dev, t->resample_epoch, out);
+    if (t->prm.kld)
+      pftk_resample_kld(t->stream, t->prm, t->dev, t->resample_epoch, out, nullptr, nullptr, nullptr);
+    else
+      pftk_resample(t->stream, t->prm, t->dev, t->resample_epoch, out);
   }
   t->resample_epoch++;
   t->cur = 1 - t->cur;
@@ -630,13 +698,15 @@ extern "C" int pft_compute(pft_tracker* t) {
   for (int it = 0; it < t->cfg.iteration_num; it++) {
     if (t->changed) stage_resample(t);
     sync_dev(t);
-    stage_aabb(t, t->dev, t->prm.P_local, false);
-    stage_crop_octree_likelihood(t, t->dev, t->prm.P_local, false, true);
+    // KLD variant: launches are sized for the capacity, the kernels take particle_num_ from PftHeader::p_active
+    const uint32_t np = t->prm.kld ? t->Pcap : t->prm.P_local;
+    stage_aabb(t, t->dev, np, false);
+    stage_crop_octree_likelihood(t, t->dev, np, false, true);
     {
       ProfScope ps(t, PFT_K_POPULATION);
       // raw weights from the partial sums, then weight()'s normalizeWeight(); use_change_detector_ == false
       // => changed_ = true => update(); the alias prefix form feeds the next resample
-      pftk_population(t->stream, t->prm, t->dev, t->prm.P_total, 1, 1, 1, 1);
+      pftk_population(t->stream, t->prm, t->dev, t->prm.kld ? t->Pcap : t->prm.P_total, 1, 1, 1, 1);
     }
     t->changed = true;
   }
@@ -724,6 +794,13 @@ extern "C" int pft_get_fit_ratio(pft_tracker* t, double* out) {
 extern "C" int pft_get_particles(pft_tracker* t, pft_particle* out, size_t cap, size_t* n) {
   if (!t) return PFT_ERR_INVALID_ARG;
   size_t P = t->initialized ? t->prm.P_total : 0;
+  if (P && t->prm.kld) {  // particle_num_ of the KLD variant lives on the device
+    uint32_t pa = 0;
+    sync_dev(t);
+    HIPCHK(t, hipMemcpyAsync(&pa, &t->d_hdr->p_active, sizeof(pa), hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(t, hipStreamSynchronize(t->stream));
+    P = pa;
+  }
   if (n) *n = P;
   if (!out || !P) return PFT_OK;
   size_t c = cap < P ? cap : P;
@@ -1031,6 +1108,49 @@ extern "C" int pft_debug_pose_to_matrix(pft_tracker* t, const pft_particle* p, s
   }
   if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
   hipFree(d); hipFree(dm);
+  HIPCHK(t, e);
+  return PFT_OK;
+}
+
+extern "C" int pft_debug_kld_resample(pft_tracker* t, const pft_particle* old, size_t n_old, const int32_t* a,
+                                      const double* q, const pft_particle* motion, uint32_t epoch, pft_particle* out,
+                                      int32_t* bins6, uint32_t* n_out, uint32_t* k_out) {
+  if (!t || !old || !n_old || !a || !q || !motion || !out || !n_out) return PFT_ERR_INVALID_ARG;
+  if (!t->prm.kld) return PFT_ERR_STATE;
+  const uint32_t maxn = t->prm.kld_max;
+  pft_particle *d_old = nullptr, *d_out = nullptr;
+  int32_t *d_a = nullptr, *d_bins = nullptr;
+  double* d_q = nullptr;
+  PftHeader* h = new PftHeader();
+  memset(h, 0, sizeof(*h));
+  h->p_active = (uint32_t)n_old;
+  h->motion = *motion;
+  hipError_t e = dalloc(&d_old, n_old);
+  if (e == hipSuccess) e = dalloc(&d_out, maxn);
+  if (e == hipSuccess) e = dalloc(&d_a, n_old);
+  if (e == hipSuccess) e = dalloc(&d_q, n_old);
+  if (e == hipSuccess) e = dalloc(&d_bins, (size_t)6 * maxn);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_old, old, n_old * sizeof(pft_particle), hipMemcpyHostToDevice, t->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_a, a, n_old * sizeof(int32_t), hipMemcpyHostToDevice, t->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_q, q, n_old * sizeof(double), hipMemcpyHostToDevice, t->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(t->d_dbg_hdr, h, sizeof(PftHeader), hipMemcpyHostToDevice, t->stream);
+  if (e == hipSuccess) {
+    PftDev d = t->dev;
+    d.part_all = d_old;
+    d.hdr = t->d_dbg_hdr;
+    d.mats = nullptr;
+    pftk_resample_kld(t->stream, t->prm, d, epoch, d_out, d_a, d_q, d_bins);
+    e = hipMemcpyAsync(h, t->d_dbg_hdr, sizeof(PftHeader), hipMemcpyDeviceToHost, t->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+  if (e == hipSuccess) {
+    *n_out = h->p_active;
+    if (k_out) *k_out = h->kld_k;
+    e = hipMemcpy(out, d_out, (size_t)h->p_active * sizeof(pft_particle), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && bins6) e = hipMemcpy(bins6, d_bins, (size_t)h->p_active * 6 * sizeof(int32_t), hipMemcpyDeviceToHost);
+  }
+  hipFree(d_old); hipFree(d_out); hipFree(d_a); hipFree(d_q); hipFree(d_bins);
+  delete h;
   HIPCHK(t, e);
   return PFT_OK;
 }

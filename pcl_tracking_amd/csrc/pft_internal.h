@@ -50,6 +50,13 @@ struct PftParams {  // immutable per handle, passed by value to kernels
   uint32_t seed_lo, seed_hi;
   uint32_t P_total, P_local, id_offset;
   uint32_t M, nchunk;
+  // KLD-adaptive variant (KLDAdaptiveParticleFilterOMPTracker, auto_tracking.cpp:207-222)
+  uint32_t kld;          // 1: the particle count changes at every resample and lives in PftHeader::p_active
+  uint32_t kld_max;      // maximum_particle_number_
+  double kld_z;          // normalQuantile(delta_), evaluated on the host
+  double kld_eps;        // epsilon_
+  float kld_bin[6];      // bin_size_ (a ParticleXYZRPY upstream: floats)
+  double motion_ratio;   // motion_ratio_
 };
 
 struct PftHeader {  // lives in HBM; written by kernels, read by later kernels (and by the host for debug)
@@ -79,6 +86,8 @@ struct PftHeader {  // lives in HBM; written by kernels, read by later kernels (
   pft_particle rep;
   pft_particle motion;
   uint32_t alias_m, alias_nh;   // sizes of the small / large lists
+  uint32_t p_active;            // KLD variant: current particle_num_ (written by init / k_resample_kld)
+  uint32_t kld_k;               // KLD variant: distinct bins of the last resample (diagnostic)
   unsigned long long stat_queries, stat_scanned;
   unsigned long long dbg[32];    // debug-variant likelihood statistics (tools/descent_stats.py)
   unsigned long long ticks[32];  // wall_clock64() (100 MHz) at phase boundaries: [0..15] octree, [16..31] population
@@ -115,6 +124,9 @@ struct PftDev {  // device pointers (host-side struct, passed by value)
   uint32_t* alias_pos;   // [P]
   double* pop_part;      // [PFT_POPM_MAX_WGS][16] per-workgroup partials of the many-workgroup population path
   PftHeader* hdr;
+  const uint32_t* p_active;  // KLD variant: &hdr->p_active (kernels take the particle count from here), else null
+  uint32_t* kld_table;       // KLD variant: open-addressing table of first occurrences, 2 x pow2(kld_max) entries
+  int32_t* kld_bins;         // KLD variant: 6 ints per candidate
   uint32_t* host_stat;  // pinned host memory, device-visible: [0] last n_crop, [1] last octree depth (read by the
                         // host WITHOUT synchronising, to pick the builder for the next iteration)
   int32_t* nn_idx;      // debug only
@@ -133,6 +145,10 @@ void pftk_resample_table(hipStream_t s, const PftParams& p, const pft_particle* 
                          const double* q, const PftHeader* hdr, uint32_t epoch, pft_particle* out);
 void pftk_pose_to_matrix(hipStream_t s, const pft_particle* p, uint32_t n, float* mats);
 void pftk_aabb(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, bool finalize);
+// KLD variant: draws up to p.kld_max candidates from d.part_all[0 .. p_active) (alias prefix form, or the explicit
+// table a/q when given), keeps the prefix the KL bound asks for, writes particles + matrices and the new p_active
+void pftk_resample_kld(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t epoch, pft_particle* out,
+                       const int32_t* table_a, const double* table_q, int32_t* bins_out);
 void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d, bool bbox_from_partials);
 void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d);
 struct SortBufs {

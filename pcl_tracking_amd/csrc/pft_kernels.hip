@@ -32,6 +32,7 @@ __global__ void k_init_particles(PftParams p, pft_particle rep, pft_particle* __
     hdr->rep = rep;
     pft_particle z = {0, 0, 0, 1.0f, 0, 0, 0, 0};
     hdr->motion = z;
+    hdr->p_active = p.P_total;
   }
   if (li >= p.P_local) return;
   pft_particle q = {0, 0, 0, 1.0f, 0, 0, 0, 0};
@@ -109,8 +110,10 @@ __global__ void k_pose_to_matrix(const pft_particle* __restrict__ p, uint32_t n,
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_aabb(const float4* __restrict__ ref, uint32_t M,
                                                const float* __restrict__ mats, uint32_t n_particles,
-                                               float* __restrict__ part, uint32_t lds_points) {
+                                               float* __restrict__ part, uint32_t lds_points,
+                                               const uint32_t* __restrict__ dyn_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (dyn_n) n_particles = *dyn_n;  // KLD variant: particle_num_ lives on the device
   __shared__ float s_red[6][16];
   float4* lref = reinterpret_cast<float4*>(smem);
   const int lane = lane_id(), w = wave_id(), nw = blockDim.x >> 6;
@@ -348,7 +351,7 @@ void pftk_aabb(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_pa
   uint32_t lds_points = lds_max / 16u;
   uint32_t lds = p.M <= lds_points ? p.M * 16u : 0u;
   hipLaunchKernelGGL(k_aabb, dim3(d.bbox_grid), dim3(1024), lds, s, d.ref_xyz, p.M, d.mats, n_particles, d.bbox_part,
-                     lds_points);
+                     lds_points, d.p_active);
   if (finalize) hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(512), 0, s, d.bbox_part, d.bbox_grid, d.bbox6);
 }
 void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d, bool from_part) {

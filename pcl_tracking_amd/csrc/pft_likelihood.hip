@@ -283,6 +283,7 @@ __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * 
   const int allow_fast = flags & 1, abl = flags >> 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const PftHeader* hdr = d.hdr;
+  if (d.p_active) n_particles = *d.p_active;  // KLD variant: particle_num_ lives on the device
   const int D = hdr->depth;
   const uint32_t n_crop = (hdr->error || D <= 0) ? 0u : hdr->n_crop;
   const uint32_t n_words = hdr->n_words;

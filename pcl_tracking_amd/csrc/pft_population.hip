@@ -494,6 +494,7 @@ __global__ __launch_bounds__(PFT_POP_THREADS) void k_population(PftParams prm, P
                                                                int from_partials, int do_norm, int do_mean,
                                                                int do_alias) {
   __shared__ PopSh S;
+  if (d.p_active) n = *d.p_active;  // KLD variant: particle_num_ lives on the device
   const uint32_t per = (n + PFT_POP_THREADS - 1) / PFT_POP_THREADS;
   if (per <= 1) population_body<1>(prm, d, n, from_partials, do_norm, do_mean, do_alias, S);
   else if (per <= 2) population_body<2>(prm, d, n, from_partials, do_norm, do_mean, do_alias, S);

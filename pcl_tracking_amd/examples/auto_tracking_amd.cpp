@@ -3,7 +3,7 @@
 // re-centre, setReferenceCloud, setTrans) and the per-frame loop (:688-697: setInputCloud, compute), followed
 // by what drawResult() does with the pose (:309-316: toEigenMatrix(getResult())).
 //
-//   auto_tracking_amd <model.bin> <frame0.bin> [frame1.bin ...] [--particles N] [--seed S] [--raw]
+//   auto_tracking_amd <model.bin> <frame0.bin> [frame1.bin ...] [--particles N] [--seed S] [--raw] [--kld]
 //
 // *.bin = raw arrays of 32-byte pcl::PointXYZRGBA records (what a binary PCD body of x y z rgba holds).
 // The model is the segmented object cluster in the camera frame.  Without --raw the frames are already
@@ -62,15 +62,16 @@ int main(int argc, char** argv) {
   std::vector<const char*> files;
   int particles = 400;
   uint64_t seed = 1;
-  bool raw = false;
+  bool raw = false, use_fixed_ = true;  // the reference defaults to use_fixed = false (:821); --kld selects that branch
   for (int i = 1; i < argc; i++) {
     if (!std::strcmp(argv[i], "--raw")) raw = true;
+    else if (!std::strcmp(argv[i], "--kld")) use_fixed_ = false;
     else if (!std::strcmp(argv[i], "--particles") && i + 1 < argc) particles = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--seed") && i + 1 < argc) seed = std::strtoull(argv[++i], nullptr, 10);
     else files.push_back(argv[i]);
   }
   if (files.size() < 2) {
-    std::fprintf(stderr, "usage: %s <model.bin> <frame.bin>... [--particles N] [--seed S] [--raw]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s <model.bin> <frame.bin>... [--particles N] [--seed S] [--raw] [--kld]\n", argv[0]);
     return 2;
   }
 
@@ -83,9 +84,24 @@ int main(int argc, char** argv) {
   std::vector<double> default_initial_mean(6, 0.0);
 
   std::shared_ptr<ParticleFilter> tracker_;
-  {
+  if (use_fixed_) {
     std::shared_ptr<ParticleFilterOMPTracker<RefPointType, ParticleT>> tracker(
         new ParticleFilterOMPTracker<RefPointType, ParticleT>(16));
+    tracker_ = tracker;
+  } else {  // :207-222
+    std::shared_ptr<KLDAdaptiveParticleFilterOMPTracker<RefPointType, ParticleT>> tracker(
+        new KLDAdaptiveParticleFilterOMPTracker<RefPointType, ParticleT>(16));
+    tracker->setMaximumParticleNum(500);
+    tracker->setDelta(0.99);
+    tracker->setEpsilon(0.2);
+    ParticleT bin_size;
+    bin_size.x = 0.1f;
+    bin_size.y = 0.1f;
+    bin_size.z = 0.1f;
+    bin_size.roll = 0.1f;
+    bin_size.pitch = 0.1f;
+    bin_size.yaw = 0.1f;
+    tracker->setBinSize(bin_size);
     tracker_ = tracker;
   }
   tracker_->setTrans(Affine3f::Identity());

@@ -2,6 +2,7 @@
 // that /root/reference/src/auto_tracking.cpp instantiates and calls on its hot path:
 //
 //   pcl::tracking::ParticleFilterOMPTracker<RefPointType, ParticleT>      :203-204
+//   pcl::tracking::KLDAdaptiveParticleFilterOMPTracker<...>               :207-222 (the runtime default, :821)
 //   pcl::tracking::ParticleFilterTracker<RefPointType, ParticleT>         :153 (base type of tracker_dict)
 //   pcl::tracking::ApproxNearestPairPointCloudCoherence<RefPointType>     :235-236
 //   pcl::tracking::DistanceCoherence / HSVColorCoherence                  :240-247
@@ -316,6 +317,27 @@ template <typename PointInT, typename StateT>
 class ParticleFilterOMPTracker : public ParticleFilterTracker<PointInT, StateT> {
  public:
   explicit ParticleFilterOMPTracker(unsigned int nr_threads = 0) : threads_(nr_threads) {}
+  unsigned int getNumberOfThreads() const { return threads_; }
+
+ private:
+  unsigned int threads_;
+};
+
+// the class the reference news unless use_fixed is set (auto_tracking.cpp:207-222, default :821): particle_num is
+// the initial count, every resample draws until the KL bound is met (at most setMaximumParticleNum)
+template <typename PointInT, typename StateT>
+class KLDAdaptiveParticleFilterOMPTracker : public ParticleFilterTracker<PointInT, StateT> {
+ public:
+  explicit KLDAdaptiveParticleFilterOMPTracker(unsigned int nr_threads = 0) : threads_(nr_threads) {
+    this->cfg_.kld_adaptive = 1;
+  }
+  void setMaximumParticleNum(unsigned int nr) { this->guard(); this->cfg_.maximum_particle_num = (int)nr; }
+  void setDelta(double delta) { this->guard(); this->cfg_.kld_delta = delta; }
+  void setEpsilon(double eps) { this->guard(); this->cfg_.kld_epsilon = eps; }
+  void setBinSize(const StateT& bin_size) {
+    this->guard();
+    for (unsigned i = 0; i < 6; i++) this->cfg_.kld_bin_size[i] = bin_size[i];
+  }
   unsigned int getNumberOfThreads() const { return threads_; }
 
  private:

@@ -325,9 +325,62 @@ class ParticleFilterTracker:
         return out
 
 
-def make_reference_tracker(particle_num=400, seed=1, **kw):
-    """A tracker configured exactly as /root/reference/src/auto_tracking.cpp:187-254 does."""
-    t = ParticleFilterTracker(threads=16, seed=seed, **kw)
+class KLDAdaptiveParticleFilterOMPTracker(ParticleFilterTracker):
+    """pcl::tracking::KLDAdaptiveParticleFilterOMPTracker<PointXYZRGBA, ParticleXYZRPY>: what auto_tracking.cpp runs
+    unless use_fixed is set (:207-222, :821).  setParticleNum is the initial count; every resample draws until the
+    KL bound is met (at most setMaximumParticleNum)."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._cfg.kld_adaptive = 1
+
+    def setMaximumParticleNum(self, n):
+        self._cfg_guard()
+        self._cfg.maximum_particle_num = int(n)
+
+    def setDelta(self, d):
+        self._cfg_guard()
+        self._cfg.kld_delta = float(d)
+
+    def setEpsilon(self, e):
+        self._cfg_guard()
+        self._cfg.kld_epsilon = float(e)
+
+    def setBinSize(self, bin_size):
+        """bin_size: the six pose steps (x, y, z, roll, pitch, yaw), a ParticleXYZRPY upstream"""
+        self._cfg_guard()
+        if hasattr(bin_size, "dtype") and bin_size.dtype == PARTICLE_DTYPE:
+            bin_size = [float(np.asarray(bin_size).reshape(-1)[0][k]) for k in ("x", "y", "z", "roll", "pitch", "yaw")]
+        for i in range(6):
+            self._cfg.kld_bin_size[i] = float(bin_size[i])
+
+    def debugKldResample(self, old, a, q, motion, epoch):
+        """test hook: the KLD resample alone, with an explicit alias table -> (particles, bins (n,6), k)"""
+        self._ensure()
+        old = np.ascontiguousarray(old, PARTICLE_DTYPE)
+        a = np.ascontiguousarray(a, np.int32)
+        q = np.ascontiguousarray(q, np.float64)
+        motion = np.ascontiguousarray(motion, PARTICLE_DTYPE).reshape(1)
+        cap = self._cfg.maximum_particle_num
+        out = np.zeros(cap, PARTICLE_DTYPE)
+        bins = np.zeros((cap, 6), np.int32)
+        n, k = C.c_uint32(), C.c_uint32()
+        self._check(self._L.pft_debug_kld_resample(self._h, _ptr(old), len(old), _ptr(a), _ptr(q), _ptr(motion), epoch,
+                                                   _ptr(out), _ptr(bins), C.byref(n), C.byref(k)))
+        return out[:n.value].copy(), bins[:n.value].copy(), k.value
+
+
+def make_reference_tracker(particle_num=400, seed=1, kld=False, **kw):
+    """A tracker configured exactly as /root/reference/src/auto_tracking.cpp:187-254 does; kld=True takes the
+    use_fixed == false branch (:207-222), the reference's runtime default."""
+    if kld:
+        t = KLDAdaptiveParticleFilterOMPTracker(threads=16, seed=seed, **kw)
+        t.setMaximumParticleNum(500)
+        t.setDelta(0.99)
+        t.setEpsilon(0.2)
+        t.setBinSize([0.1] * 6)
+    else:
+        t = ParticleFilterTracker(threads=16, seed=seed, **kw)
     step = [0.015 * 0.015] * 6
     step[3] *= 40.0
     step[4] *= 40.0

@@ -60,6 +60,9 @@ def test_config_defaults_are_the_reference_values(lib):
     assert c.max_distance == 0.1 and c.octree_resolution == 0.01 and c.hsv_weight == 0.1
     assert (c.alpha, c.distance_weight, c.h_weight, c.s_weight, c.v_weight) == (15.0, 1.0, 1.0, 1.0, 0.0)
     assert c.abi_version == lib.PFT_ABI_VERSION
+    # the KLD-adaptive branch, :207-219 (off by default: the north-star path is the fixed tracker)
+    assert c.kld_adaptive == 0 and c.maximum_particle_num == 500 and (c.kld_delta, c.kld_epsilon) == (0.99, 0.2)
+    assert list(c.kld_bin_size) == [0.1] * 6 and c.motion_ratio == 0.25
 
 
 def test_host_helpers_match_oracle(lib, orc):
