@@ -64,7 +64,7 @@ def build_example(force=False, verbose=False):
     PCL classes and the C-ABI library"""
     lib = build()
     deps = [EXAMPLE_SRC, os.path.join(_HERE, "include", "pft", "particle_filter_tracker.hpp"),
-            os.path.join(_HERE, "include", "pft", "filters.hpp"), lib]
+            os.path.join(_HERE, "include", "pft", "filters.hpp"), os.path.join(_HERE, "include", "pft", "pcd_io.hpp"), lib]
     if not force and os.path.exists(EXAMPLE_BIN) and all(os.path.getmtime(d) <= os.path.getmtime(EXAMPLE_BIN) for d in deps):
         return EXAMPLE_BIN
     root = os.path.dirname(_HERE)

@@ -5,7 +5,8 @@
 //
 //   auto_tracking_amd <model.bin> <frame0.bin> [frame1.bin ...] [--particles N] [--seed S] [--raw] [--kld]
 //
-// *.bin = raw arrays of 32-byte pcl::PointXYZRGBA records (what a binary PCD body of x y z rgba holds).
+// *.pcd = PCD v0.7 ascii / binary with fields x y z rgba (what create_model.cpp:219-222 writes);
+// *.bin = raw arrays of 32-byte pcl::PointXYZRGBA records.
 // The model is the segmented object cluster in the camera frame.  Without --raw the frames are already
 // filtered and downsampled; with --raw they are sensor frames and go through cloud_cb's front end first
 // (:637 filterPassThrough, :683 gridSampleApprox) on the device, the result staying in HBM for the tracker.
@@ -18,6 +19,7 @@
 #include <vector>
 
 #include "pft/filters.hpp"
+#include "pft/pcd_io.hpp"
 #include "pft/particle_filter_tracker.hpp"
 
 using namespace pft;
@@ -30,6 +32,14 @@ typedef ParticleFilterTracker<RefPointType, ParticleT> ParticleFilter;
 
 static Cloud::Ptr load_bin(const char* path) {
   Cloud::Ptr c(new Cloud());
+  const size_t len = std::strlen(path);
+  if (len > 4 && !std::strcmp(path + len - 4, ".pcd")) {  // what create_model.cpp:219-222 writes (:741 loadPCDFile)
+    if (pft::io::loadPCDFile(path, *c) == -1) {
+      std::fprintf(stderr, "pcd file not found or not readable: %s\n", path);
+      c->points.clear();
+    }
+    return c;
+  }
   FILE* f = std::fopen(path, "rb");
   if (!f) {
     std::fprintf(stderr, "cannot open %s\n", path);
@@ -62,16 +72,18 @@ int main(int argc, char** argv) {
   std::vector<const char*> files;
   int particles = 400;
   uint64_t seed = 1;
+  double downsampling_grid_size_ = 0.01;  // :824; --model-leaf 0 skips gridSample of the model
   bool raw = false, use_fixed_ = true;  // the reference defaults to use_fixed = false (:821); --kld selects that branch
   for (int i = 1; i < argc; i++) {
     if (!std::strcmp(argv[i], "--raw")) raw = true;
     else if (!std::strcmp(argv[i], "--kld")) use_fixed_ = false;
+    else if (!std::strcmp(argv[i], "--model-leaf") && i + 1 < argc) downsampling_grid_size_ = std::atof(argv[++i]);
     else if (!std::strcmp(argv[i], "--particles") && i + 1 < argc) particles = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--seed") && i + 1 < argc) seed = std::strtoull(argv[++i], nullptr, 10);
     else files.push_back(argv[i]);
   }
   if (files.size() < 2) {
-    std::fprintf(stderr, "usage: %s <model.bin> <frame.bin>... [--particles N] [--seed S] [--raw] [--kld]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s <model.bin> <frame.bin>... [--particles N] [--seed S] [--raw] [--kld] [--model-leaf L]\n", argv[0]);
     return 2;
   }
 
@@ -156,8 +168,21 @@ int main(int argc, char** argv) {
     p.y -= (float)cy;
     p.z -= (float)cz;
   }
-  tracker_->setReferenceCloud(transed_ref);
+  Cloud::Ptr transed_ref_downsampled(new Cloud());
+  if (downsampling_grid_size_ > 0) {  // gridSample (:549-561, :672): pcl::VoxelGrid on the device
+    pft::VoxelGrid grid;
+    const float leaf = (float)downsampling_grid_size_;
+    grid.setLeafSize(leaf, leaf, leaf);
+    grid.setInputCloud(transed_ref);
+    grid.filter(*transed_ref_downsampled);
+  } else {
+    *transed_ref_downsampled = *transed_ref;
+  }
+  std::fprintf(stderr, "ref_cloud: %zu data points, nonzero_ref: %zu, downsampled: %zu\n", ref_cloud->points.size(),
+               nonzero_ref->points.size(), transed_ref_downsampled->points.size());
+  tracker_->setReferenceCloud(transed_ref_downsampled);
   tracker_->setTrans(trans);
+  const Cloud::Ptr reference_ = transed_ref;  // reference_dict[obj_id] (:675): the full-resolution model, for drawResult
   tracker_->setMinIndices((int)ref_cloud->points.size() / 2);
 
   // ---- "track the object", auto_tracking.cpp:688-697, then drawResult :309-310 ----
@@ -178,9 +203,18 @@ int main(int argc, char** argv) {
     tracker_->compute();
     ParticleXYZRPY result = tracker_->getResult();
     Affine3f transformation = tracker_->toEigenMatrix(result);
-    std::printf("frame %zu pose %.6f %.6f %.6f %.6f %.6f %.6f  t = [%.5f %.5f %.5f]\n", f, result.x, result.y,
-                result.z, result.roll, result.pitch, result.yaw, transformation(0, 3), transformation(1, 3),
-                transformation(2, 3));
+    // drawResult (:309-316) + viz_cb (:432-466): the full-resolution model moved by the result pose and its
+    // centroid, which the node publishes as the object position
+    float sx = 0, sy = 0, sz = 0;
+    for (const auto& p : reference_->points) {
+      sx += transformation(0, 0) * p.x + transformation(0, 1) * p.y + transformation(0, 2) * p.z + transformation(0, 3);
+      sy += transformation(1, 0) * p.x + transformation(1, 1) * p.y + transformation(1, 2) * p.z + transformation(1, 3);
+      sz += transformation(2, 0) * p.x + transformation(2, 1) * p.y + transformation(2, 2) * p.z + transformation(2, 3);
+    }
+    const float nref = (float)reference_->points.size();
+    std::printf("frame %zu pose %.6f %.6f %.6f %.6f %.6f %.6f  t = [%.5f %.5f %.5f]  centroid = [%.5f %.5f %.5f]\n", f,
+                result.x, result.y, result.z, result.roll, result.pitch, result.yaw, transformation(0, 3),
+                transformation(1, 3), transformation(2, 3), sx / nref, sy / nref, sz / nref);
   }
   return 0;
 }

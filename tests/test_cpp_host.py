@@ -56,7 +56,7 @@ def test_cpp_driver_matches_python_binding(tmp_path):
     for i, fr in enumerate(frames):
         fr.tofile(tmp_path / ("frame%d.bin" % i))
         paths.append(str(tmp_path / ("frame%d.bin" % i)))
-    r = subprocess.run([exe, str(tmp_path / "model.bin")] + paths + ["--particles", "1000", "--seed", "6"],
+    r = subprocess.run([exe, str(tmp_path / "model.bin")] + paths + ["--particles", "1000", "--seed", "6", "--model-leaf", "0"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     got = [list(map(float, line.split("pose")[1].split("t =")[0].split())) for line in r.stdout.splitlines()
@@ -106,7 +106,7 @@ def test_cpp_driver_raw_frames_go_through_the_device_front_end(tmp_path):
     down.tofile(tmp_path / "down.bin")
     outs, errs = [], []
     for args in ([str(tmp_path / "raw.bin"), "--raw"], [str(tmp_path / "down.bin")]):
-        r = subprocess.run([exe, str(tmp_path / "model.bin")] + args + ["--particles", "600", "--seed", "2"],
+        r = subprocess.run([exe, str(tmp_path / "model.bin")] + args + ["--particles", "600", "--seed", "2", "--model-leaf", "0"],
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
         outs.append([line for line in r.stdout.splitlines() if line.startswith("frame")])
@@ -129,7 +129,7 @@ def test_cpp_driver_kld_branch_matches_python_binding(tmp_path):
     model.tofile(tmp_path / "model.bin")
     frame.tofile(tmp_path / "frame.bin")
     r = subprocess.run([exe, str(tmp_path / "model.bin"), str(tmp_path / "frame.bin"), str(tmp_path / "frame.bin"),
-                        "--kld", "--seed", "8"], capture_output=True, text=True, timeout=300)
+                        "--kld", "--seed", "8", "--model-leaf", "0"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     got = [list(map(float, line.split("pose")[1].split("t =")[0].split())) for line in r.stdout.splitlines()
            if line.startswith("frame")]
@@ -153,3 +153,77 @@ def test_cpp_driver_kld_branch_matches_python_binding(tmp_path):
         t.compute()
         res = t.getResult()
         np.testing.assert_allclose(got[f], [float(res[k]) for k in ("x", "y", "z", "roll", "pitch", "yaw")], atol=2e-6)
+
+
+def write_pcd(path, cloud, binary):
+    """PCD v0.7 with FIELDS x y z rgba, as pcl::PCDWriter::write<PointXYZRGBA> lays it out"""
+    n = len(cloud)
+    hdr = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgba\nSIZE 4 4 4 4\nTYPE F F F U\n"
+           "COUNT 1 1 1 1\nWIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA %s\n" % (n, n, "binary" if binary else "ascii"))
+    with open(path, "wb") as f:
+        f.write(hdr.encode())
+        if binary:
+            rec = np.zeros(n, np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("rgba", "<u4")]))
+            for k in ("x", "y", "z", "rgba"):
+                rec[k] = cloud[k]
+            f.write(rec.tobytes())
+        else:
+            for p in cloud:
+                f.write(("%.9g %.9g %.9g %d\n" % (p["x"], p["y"], p["z"], p["rgba"])).encode())
+
+
+@pytest.mark.gpu
+def test_cpp_driver_pcd_models_gridsample_and_centroid(tmp_path):
+    """PCD model in (ascii and binary), removeZeroPoints -> centroid -> re-centre -> gridSample
+    (VoxelGrid on the device, :672) -> tracking -> drawResult's centroid of the moved full-resolution model"""
+    from pcl_tracking_amd import build, filters, tracker
+
+    exe = build.build_example()
+    model = scene.make_model(4000)
+    off = np.array(scene.model_gt_pose()[:3], np.float32)
+    for k, name in enumerate(("x", "y", "z")):
+        model[name] = model[name] + off[k]
+    frame = scene.make_scene(50000)[:20000]
+    write_pcd(tmp_path / "m_ascii.pcd", model, False)
+    write_pcd(tmp_path / "m_bin.pcd", model, True)
+    model.tofile(tmp_path / "m.bin")
+    frame.tofile(tmp_path / "frame.bin")
+    outs = []
+    for m in ("m_ascii.pcd", "m_bin.pcd", "m.bin"):
+        r = subprocess.run([exe, str(tmp_path / m), str(tmp_path / "frame.bin"), "--seed", "5"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append([line for line in r.stdout.splitlines() if line.startswith("frame")])
+        assert "downsampled:" in r.stderr
+    assert len(outs[0]) == 1 and outs[0] == outs[1] == outs[2]  # %.9g round-trips float32
+    # the same in Python: float centroid, re-centre, VoxelGrid(0.01) on the device, track, centroid of the moved model
+    s = np.zeros(3, np.float32)
+    for p in model:
+        s[0] += p["x"]
+        s[1] += p["y"]
+        s[2] += p["z"]
+    c = s / np.float32(len(model))
+    ref = model.copy()
+    for k, name in enumerate(("x", "y", "z")):
+        ref[name] = ref[name] - c[k]
+    g = filters.VoxelGrid()
+    g.setLeafSize(0.01)
+    g.setInputCloud(ref)
+    down = g.filter()
+    assert len(down) < len(ref)
+    trans = np.eye(4, dtype=np.float32)
+    trans[:3, 3] = c
+    t = tracker.make_reference_tracker(particle_num=400, seed=5)
+    t.setReferenceCloud(down)
+    t.setTrans(trans)
+    t.setInputCloud(frame)
+    t.compute()
+    res = t.getResult()
+    line = outs[0][0]
+    got = list(map(float, line.split("pose")[1].split("t =")[0].split()))
+    np.testing.assert_allclose(got, [float(res[k]) for k in ("x", "y", "z", "roll", "pitch", "yaw")], atol=2e-6)
+    T = t.toEigenMatrix(res)
+    xyz = np.stack([ref["x"], ref["y"], ref["z"]], 1).astype(np.float64)
+    want_c = (xyz @ np.asarray(T, np.float64)[:3, :3].T + np.asarray(T, np.float64)[:3, 3]).mean(0)
+    got_c = list(map(float, line.split("centroid = [")[1].rstrip("]").split()))
+    np.testing.assert_allclose(got_c, want_c, atol=1e-4)
