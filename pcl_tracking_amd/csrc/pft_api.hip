@@ -68,6 +68,7 @@ struct pft_tracker {
   double* d_pop_part = nullptr;
   uint32_t* d_kld_table = nullptr;
   int32_t* d_kld_bins = nullptr;
+  uint32_t dbg_builds = 0;
   uint32_t Pcap = 0;  // particle capacity of the buffers (== P_total unless KLD-adaptive)
   uint32_t* d_alias_pos = nullptr;
   PftHeader* d_hdr = nullptr;
@@ -658,7 +659,11 @@ static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32
     bool sorted = last_n > PFT_SORTED_BUILD_MIN;
     if (t->force_builder == 1) sorted = false;
     if (t->force_builder == 2) sorted = true;
-    if (sorted) {
+    // timing experiments only (results are wrong while set): PFT_DEBUG_SKIP_OCTREE=1 reuses the tree of the
+    // previous build after the first 8 builds, to measure the builder's true share of a frame
+    static const bool skip_env = getenv("PFT_DEBUG_SKIP_OCTREE") != nullptr;
+    if (skip_env && ++t->dbg_builds > 8) {
+    } else if (sorted) {
       // 8-bit passes for 3 bits per level; one level of head-room over the last depth (k_so_scan flags an error
       // if the tree turned out deeper than the passes cover)
       int npass = last_depth > 0u ? (int)((3u * (last_depth + 1u) + 7u) / 8u) : 8;
