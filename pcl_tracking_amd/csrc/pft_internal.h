@@ -32,7 +32,7 @@
 #define PFT_LIK_WGS_PER_CU 2    // resident likelihood workgroups per CU (each gets 1/N of the LDS)
 #endif
 #define PFT_POP_THREADS 1024
-#define PFT_SORTED_BUILD_MIN 16000  // cropped points (last iteration) above which the sorted builder is used
+#define PFT_SORTED_BUILD_MIN 18000  // cropped points (last iteration) above which the sorted builder is used
 #define PFT_POPM_THREADS 256
 #define PFT_POPM_ITEMS 16   // many-workgroup population path: 4096 particles per workgroup
 #define PFT_POPM_MAX_WGS 256

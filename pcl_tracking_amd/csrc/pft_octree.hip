@@ -168,6 +168,27 @@ struct RegStore {
   }
 };
 
+// registers for the first K*1024 points, L2-resident arrays for the rest: crops a little above the register range
+template <int K>
+struct HybridStore {
+  typedef uint32_t key_t;
+  static constexpr int B = 10;
+  uint32_t key[K], node[K];
+  uint32_t* gkey;
+  uint32_t* gnode;
+  __device__ HybridStore(const PftDev& d) : gkey(reinterpret_cast<uint32_t*>(d.pt_key64)), gnode(d.pt_node) {}
+  template <class F>
+  __device__ __forceinline__ void each(uint32_t n, F&& f) {
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      uint32_t i = threadIdx.x + j * PFT_BUILD_THREADS;
+      if (i < n) f(i, key[j], node[j]);
+      UNROLL_FENCE(j, 2);
+    }
+    for (uint32_t i = K * PFT_BUILD_THREADS + threadIdx.x; i < n; i += PFT_BUILD_THREADS) f(i, gkey[i], gnode[i]);
+  }
+};
+
 struct GlobStore {
   typedef unsigned long long key_t;
   static constexpr int B = 21;
@@ -382,6 +403,17 @@ __device__ __forceinline__ void build_tree_any(const PftParams& prm, const PftDe
 }
 
 template <int K>
+__device__ __forceinline__ void build_hybrid(const PftParams& prm, const PftDev& d, BuildSh& S, uint32_t n, uint32_t* lds_words,
+                             uint32_t cap, uint32_t* lds_tmp, uint32_t* ls, uint32_t* nl, int* path) {
+  if (S.depth <= HybridStore<K>::B) {
+    *path = 2;
+    build_tree_any<HybridStore<K>>(prm, d, S, n, lds_words, cap, lds_tmp, ls, nl);
+  } else {
+    build_tree_any<GlobStore>(prm, d, S, n, lds_words, cap, lds_tmp, ls, nl);
+  }
+}
+
+template <int K>
 __device__ __forceinline__ void build_regs(const PftParams& prm, const PftDev& d, BuildSh& S, uint32_t n, uint32_t* lds_words,
                            uint32_t cap, uint32_t* lds_tmp, uint32_t* ls, uint32_t* nl, int* path) {
   if (S.depth <= RegStore<K>::B) {
@@ -433,6 +465,7 @@ __global__ __launch_bounds__(PFT_BUILD_THREADS) void k_octree_build(PftParams pr
     else if (n <= 8u * PFT_BUILD_THREADS) build_regs<8>(prm, d, S, n, lds_words, cap, lds_tmp, &leaf_start, &n_leaves, &path);
     // 12 points per thread is the last register-resident size without scratch (16 spills 12 VGPRs)
     else if (n <= 12u * PFT_BUILD_THREADS) build_regs<12>(prm, d, S, n, lds_words, cap, lds_tmp, &leaf_start, &n_leaves, &path);
+    else if (n <= 18u * PFT_BUILD_THREADS) build_hybrid<8>(prm, d, S, n, lds_words, cap, lds_tmp, &leaf_start, &n_leaves, &path);
     else build_tree_any<GlobStore>(prm, d, S, n, lds_words, cap, lds_tmp, &leaf_start, &n_leaves);
   }
   __syncthreads();
