@@ -115,7 +115,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("PFT_DIST_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ  # 1-rank rehearsal
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=dev)
@@ -129,11 +130,11 @@ def main():
     cloud_dev = torch.from_numpy(cloud.view(np.uint8).reshape(-1).copy()).to(dev)  # PCL 32-B layout in HBM
 
     def sync():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world == 1:
+    if world == 1 and not force_dist:
         from pcl_tracking_amd import tracker
 
         # independent objects are independent handles, each on its own HIP stream (the reference tracks them in
@@ -257,7 +258,7 @@ def main():
             out["speedup_vs_cpu"] = pips / out["cpu_baseline"]["value"]
         if world == 1 and not ARGS.no_frontend:
             out["frontend"] = frontend_measurement(dev, not ARGS.no_cpu_baseline)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:

@@ -96,6 +96,10 @@ class ShardedFilter:
         self.p = phases
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # rehearsal on one GPU: run the collectives even with a single rank (exercises the RCCL calls in stream order)
+        import os
+
+        self.force = dist.is_initialized() and os.environ.get("PFT_DIST_FORCE_COLLECTIVES") == "1"
 
         # RCCL ("nccl") takes device tensors directly.  Under gloo (CPU tests, or several ranks sharing one
         # GPU in the single-GPU rehearsal of tests/test_gpu_dist.py) device tensors are staged through the host.
@@ -122,10 +126,10 @@ class ShardedFilter:
         p.begin_frame()
         for it in range(p.iteration_num):
             p.phase_a(it)
-            if self.world > 1:
+            if self.world > 1 or self.force:
                 self._all_reduce_max(p.bbox6)
             p.phase_b()
-            if self.world > 1:
+            if self.world > 1 or self.force:
                 self._all_gather(p.gathered, p.shard)
             else:
                 p.gathered.copy_(p.shard)
