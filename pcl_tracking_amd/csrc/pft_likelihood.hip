@@ -70,7 +70,10 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
   const double maxd2 = prm.maxd2;
   const double wd = prm.dist_w, whsv = prm.hsv_w;
   const float hw = prm.h_w, sw = prm.s_w, vw = prm.v_w;
-  for (uint32_t item = gw; item < n_items; item += tw) {
+  for (uint32_t item_v = gw; item_v < n_items; item_v += tw) {
+    // the work item is wave-uniform: said explicitly, so the particle's matrix is fetched with scalar loads and
+    // lives in SGPRs
+    const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item_v);
     const uint32_t pi = item / nchunk, ch = item % nchunk;
     float T[12];
     load_matrix(d.mats, pi, T);
