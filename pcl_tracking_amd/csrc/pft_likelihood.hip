@@ -37,6 +37,15 @@ struct LikCtx {
   const uint16_t* leaf16;  // LDS: start offsets of the leaves (+ sentinel)
 };
 
+// node words when the tree outgrows LDS: the first n_lds words (the top levels, read by every descent) from LDS,
+// the rest from HBM / L2
+struct HybridWords {
+  const __attribute__((address_space(3))) uint32_t* lds;
+  const uint32_t* __restrict__ glob;
+  uint32_t n_lds;
+  __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return i < n_lds ? lds[i] : glob[i]; }
+};
+
 __device__ __forceinline__ double rcp_nr(double x) {
   // 1/x for x in [1, 2): hardware estimate + two Newton steps (full double precision up to ~1 ulp)
   double r = __builtin_amdgcn_rcp(x);
@@ -309,7 +318,11 @@ __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * 
   const uint32_t branch_bytes = leaf16 ? leaf_start * 4u : n_words * 4u;
   const uint32_t leaf_bytes = leaf16 ? ((n_leaves + 1u) * 2u + 3u) & ~3u : 0u;
   uint32_t jump_bytes = J > 0 ? (2u << (3 * J)) : 0u;
-  if ((size_t)used + jump_bytes + branch_bytes + leaf_bytes > (size_t)lds_bytes) {  // node words in LDS first
+  // everything fits: jump table + all words.  A little too big: drop the jump table.  Far too big (large crops):
+  // keep the jump table and hold only the top levels of the tree in LDS (HybridWords).
+  const bool fits_with_jump = (size_t)used + jump_bytes + branch_bytes + leaf_bytes <= (size_t)lds_bytes;
+  const bool fits_without_jump = (size_t)used + branch_bytes + leaf_bytes <= (size_t)lds_bytes;
+  if (!fits_with_jump && fits_without_jump) {
     J = 0;
     jump_bytes = 0;
   }
@@ -318,6 +331,7 @@ __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * 
   uint32_t* lwords = reinterpret_cast<uint32_t*>(smem + used);
   uint16_t* lleaf = reinterpret_cast<uint16_t*>(smem + used + branch_bytes);
   const bool words_in_lds = (size_t)used + branch_bytes + leaf_bytes <= (size_t)lds_bytes;
+  const uint32_t n_lds_words = words_in_lds ? 0u : min(n_words, (lds_bytes - used) / 4u);
 
   for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
     lut_h[i] = (float)i / 180.0f;
@@ -334,6 +348,8 @@ __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * 
     for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) lwords[i] = d.words[i];
     if (leaf16)
       for (uint32_t i = threadIdx.x; i <= n_leaves; i += blockDim.x) lleaf[i] = (uint16_t)d.words[leaf_start + i];
+  } else {
+    for (uint32_t i = threadIdx.x; i < n_lds_words; i += blockDim.x) lwords[i] = d.words[i];
   }
   __syncthreads();
 
@@ -371,7 +387,10 @@ __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * 
     else
       likelihood_items<false, false, DEBUG_NN, false>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
   } else {
-    const uint32_t* __restrict__ W = d.words;
+    HybridWords W;
+    W.lds = (const __attribute__((address_space(3))) uint32_t*)lwords;
+    W.glob = d.words;
+    W.n_lds = n_lds_words;
     if (fast)
       likelihood_items<true, true, DEBUG_NN, false>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
     else if (use_tab)
