@@ -7,7 +7,9 @@ from collections import defaultdict
 
 out = sys.argv[1]
 acc = defaultdict(lambda: defaultdict(list))
-for f in glob.glob(os.path.join(out, "g*", "**", "*counter_collection.csv"), recursive=True):
+files = glob.glob(os.path.join(out, "g*", "**", "*counter_collection.csv"), recursive=True) + \
+    glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True)
+for f in files:
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
