@@ -100,6 +100,46 @@ def frontend_measurement(dev, with_cpu):
     return out
 
 
+def reference_operating_point(model, cloud, trans, dev, with_cpu):
+    """BASELINE configs[0], reported beside the headline: the reference's own settings (auto_tracking.cpp:201-254) --
+    400 particles fixed (use_fixed) and the KLD-adaptive tracker it runs by default (<= 500 particles) -- on the same
+    model / cloud; CPU figure = the oracle with the reference's 16 OpenMP threads (:845)."""
+    from pcl_tracking_amd import tracker
+
+    out = {}
+    for name, kld in (("fixed_400", False), ("kld_adaptive_500", True)):
+        t = tracker.make_reference_tracker(particle_num=400, seed=1, kld=kld, device_id=dev.index or 0)
+        t.setReferenceCloud(model)
+        t.setTrans(trans)
+        t.setInputCloud(cloud)
+        for _ in range(20):
+            t.compute()
+        t.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(300):
+            t.compute()
+        t.synchronize()
+        ms = (time.perf_counter() - t0) / 300 * 1e3
+        out[name] = {"gpu_ms_per_frame": ms, "gpu_frames_per_s": 1e3 / ms, "particles_after": int(len(t.getParticles()))}
+        if with_cpu:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle
+
+            o = oracle.Tracker(oracle.default_config(particle_num=400, threads=16, emulate_pcl_alloc=1, seed=1,
+                                                     kld_adaptive=int(kld)))
+            o.set_reference(model)
+            o.set_trans(trans)
+            o.set_input(cloud)
+            o.compute()
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                o.compute()
+                ts.append(time.perf_counter() - t0)
+            out[name]["cpu_port_ms_per_frame_16_threads"] = min(ts) * 1e3
+    return out
+
+
 def main():
     import numpy as np
     import torch
@@ -258,6 +298,7 @@ def main():
             out["speedup_vs_cpu"] = pips / out["cpu_baseline"]["value"]
         if world == 1 and not ARGS.no_frontend:
             out["frontend"] = frontend_measurement(dev, not ARGS.no_cpu_baseline)
+            out["reference_operating_point"] = reference_operating_point(model, cloud, trans, dev, not ARGS.no_cpu_baseline)
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
