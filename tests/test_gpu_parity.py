@@ -344,3 +344,35 @@ def test_native_library_is_loaded(gpu):
     _lib.load()
     with open("/proc/%d/maps" % os.getpid()) as f:
         assert "libpft_hip.so" in f.read()
+
+
+def test_handle_survives_changing_inputs(gpu, orc, data):
+    """input clouds of very different sizes, a new reference cloud mid-run, empty input: the handle regrows its buffers
+    and keeps matching the oracle (auto_tracking.cpp feeds a different cloud every frame)"""
+    g, o = make_pair(gpu, orc, data["model"], data["scene"], 256, seed=9)
+    clouds = [data["scene"], scene.make_scene(307200, mode="organized"), data["scene"][:900], data["scene"][:20000]]
+    for c in clouds:
+        g.setInputCloud(c)
+        o.set_input(c)
+        g.compute()
+        assert o.compute() == 0
+        rg, ro = g.getResult(), o.get_result()
+        for k in ("x", "y", "z", "roll", "pitch", "yaw"):
+            assert abs(float(rg[k]) - float(ro[k])) < 1e-4, (len(c), k)
+    # a new (larger) reference cloud: the reference's "set object to track" step can be repeated
+    m2 = scene.make_model(4000, seed=5)
+    g.setReferenceCloud(m2)
+    o.set_reference(m2)
+    p = particles_around(data["gt"], 256, 2)
+    G = g.evalWeights(p)
+    O = o.eval_weights(p, mats=g.debugPoseToMatrix(p))
+    np.testing.assert_array_equal(G["crop_idx"], O["crop_idx"])
+    assert ulp_diff(G["raw"], O["raw"]).max() <= 1
+    # many short-lived handles (create / destroy cycles)
+    for k in range(20):
+        t = gpu.make_reference_tracker(particle_num=64, seed=k)
+        t.setReferenceCloud(data["model"][:200])
+        t.setTrans(scene.initial_trans())
+        t.setInputCloud(data["scene"][:3000])
+        t.compute()
+        t.close()
