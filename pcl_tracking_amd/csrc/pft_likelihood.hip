@@ -209,14 +209,23 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
       float bd = (abl & 2) ? 1.0e-3f : INFINITY;
       uint32_t bpos = ls;
       float4 bt = make_float4(0, 0, 0, 0);
-      for (uint32_t pos = ls; pos < le; pos++) {
+      for (uint32_t pos = ls; pos < le; pos += 2) {  // two candidates per round: their gathers overlap
+        const bool two = pos + 1 < le;
         const float4 c = d.leaf_pts[pos];
+        const float4 c2 = d.leaf_pts[two ? pos + 1 : pos];
         float dx = c.x - qx, dy = c.y - qy, dz = c.z - qz;
         float dd = dx * dx + (dy * dy + dz * dz);
         if (dd < bd) {
           bd = dd;
           bpos = pos;
           bt = c;
+        }
+        dx = c2.x - qx; dy = c2.y - qy; dz = c2.z - qz;
+        dd = dx * dx + (dy * dy + dz * dz);
+        if (two && dd < bd) {
+          bd = dd;
+          bpos = pos + 1;
+          bt = c2;
         }
       }
       if (DEBUG_NN) {

@@ -11,8 +11,9 @@ from pcl_tracking_amd import scene, tracker  # noqa: E402
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 reps = 10
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 50000
 model = scene.make_model(2048)
-cloud = scene.make_scene(50000)
+cloud = scene.make_scene(N, mode="organized" if N == 307200 else "voxel")
 t = tracker.make_reference_tracker(particle_num=P, seed=1)
 t.setReferenceCloud(model)
 t.setTrans(scene.initial_trans())
