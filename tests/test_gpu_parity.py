@@ -376,3 +376,66 @@ def test_handle_survives_changing_inputs(gpu, orc, data):
         t.setInputCloud(data["scene"][:3000])
         t.compute()
         t.close()
+
+
+# ---- non-default parameters: everything a caller of the PCL classes can set ---------------------------------
+@pytest.mark.parametrize("params", [
+    dict(octree_resolution=0.02, max_distance=0.05),
+    dict(octree_resolution=0.005, max_distance=0.2, distance_weight=4.0),
+    dict(hsv_weight=1.5, h_weight=0.5, s_weight=2.0, v_weight=1.0),
+    dict(hsv_pcl180_argorder=0, alpha=5.0),
+    dict(octree_resolution=0.037, max_distance=0.01, hsv_weight=0.0),
+])
+def test_eval_weights_non_default_parameters(gpu, orc, data, params):
+    P = 96
+    o = orc.Tracker(orc.default_config(particle_num=P, threads=0, emulate_pcl_alloc=0, **params))
+    g = gpu.ParticleFilterTracker(seed=1)
+    g.setParticleNum(P)
+    coh = gpu.ApproxNearestPairPointCloudCoherence()
+    dc, hc = gpu.DistanceCoherence(), gpu.HSVColorCoherence()
+    dc.setWeight(params.get("distance_weight", 1.0))
+    hc.setWeight(params.get("hsv_weight", 0.1))
+    hc.setHWeight(params.get("h_weight", 1.0))
+    hc.setSWeight(params.get("s_weight", 1.0))
+    hc.setVWeight(params.get("v_weight", 0.0))
+    coh.addPointCoherence(dc)
+    coh.addPointCoherence(hc)
+    coh.setSearchMethod(gpu.OctreeSearch(params.get("octree_resolution", 0.01)))
+    coh.setMaximumDistance(params.get("max_distance", 0.1))
+    g.setCloudCoherence(coh)
+    g.setAlpha(params.get("alpha", 15.0))
+    g._cfg.hsv_pcl180_argorder = params.get("hsv_pcl180_argorder", 1)
+    for ref, tr, inp in ((g.setReferenceCloud, g.setTrans, g.setInputCloud), (o.set_reference, o.set_trans, o.set_input)):
+        ref(data["model"])
+        tr(scene.initial_trans())
+        inp(data["scene"])
+    p = particles_around(data["gt"], P, 17)
+    G = g.evalWeights(p, want_nn=True)
+    O = o.eval_weights(p, want_nn=True, mats=g.debugPoseToMatrix(p))
+    np.testing.assert_array_equal(G["crop_idx"], O["crop_idx"])
+    assert G["octree_depth"] == O["octree_depth"]
+    np.testing.assert_array_equal(G["nn_idx"], O["nn_idx"])
+    np.testing.assert_array_equal(G["nn_d2"], O["nn_d2"])
+    d = ulp_diff(G["raw"], O["raw"])
+    assert d.max() <= 1, d.max()
+    # A8 with the configured alpha
+    w_o, fit_o = orc.normalize_weights(O["raw"], alpha=params.get("alpha", 15.0))
+    w_g, fit_g = g.debugNormalize(O["raw"])
+    assert fit_g == fit_o and ulp_diff(w_g, w_o).max() <= 1
+
+
+@pytest.mark.parametrize("iters", [1, 3])
+def test_compute_other_iteration_counts(gpu, orc, data, iters):
+    g = gpu.make_reference_tracker(particle_num=300, seed=12)
+    g.setIterationNum(iters)
+    o = orc.Tracker(orc.default_config(particle_num=300, seed=12, threads=0, emulate_pcl_alloc=0, iteration_num=iters))
+    for ref, tr, inp in ((g.setReferenceCloud, g.setTrans, g.setInputCloud), (o.set_reference, o.set_trans, o.set_input)):
+        ref(data["model"])
+        tr(scene.initial_trans())
+        inp(data["scene"])
+    for f in range(3):
+        g.compute()
+        assert o.compute() == 0
+        rg, ro = g.getResult(), o.get_result()
+        for k in ("x", "y", "z", "roll", "pitch", "yaw"):
+            assert abs(float(rg[k]) - float(ro[k])) < 1e-4, (f, k)
