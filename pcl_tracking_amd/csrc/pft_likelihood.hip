@@ -104,7 +104,9 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         }
         continue;
       }
-      uint32_t node = 0, pkx = 0, pky = 0, pkz = 0;
+      // heap-numbered path key of `node` per axis: j = 2^lvl + key (1 at the root); its children's centres are the
+      // table entries 2j-2 and 2j-1, and j' = 2j + bit
+      uint32_t node = 0, jx = 1, jy = 1, jz = 1;
       int lvl = 0;
       int dbg_fast = 0, dbg_gen = 0, dbg_jump = 0, dbg_hard = 0;
       if (FAST) {
@@ -144,7 +146,8 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
           dbg_fast++;
         }
         const int up = D - lvl;
-        pkx = kx >> up; pky = ky >> up; pkz = kz >> up;  // path key of `node` (zero at the root)
+        const uint32_t top = 1u << lvl;
+        jx = (kx >> up) | top; jy = (ky >> up) | top; jz = (kz >> up) | top;
       }
       // ---- generic levels: exact float evaluation of the existing children ----
       if ((abl & 1) && lvl < D) {  // timing ablation only (PFT_ABLATE): skip the generic levels
@@ -157,13 +160,13 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         const uint32_t mask = wv & 0xffu, base = wv >> 8;
         float cx0, cx1, cy0, cy1, cz0, cz1;
         if (USE_TAB) {
-          const uint32_t off = (2u << lvl) - 2u;  // children live at level lvl + 1
-          const float2 tx2 = *reinterpret_cast<const float2*>(cx.tab + off + 2u * pkx);
-          const float2 ty2 = *reinterpret_cast<const float2*>(cx.tab + cx.per_axis + off + 2u * pky);
-          const float2 tz2 = *reinterpret_cast<const float2*>(cx.tab + 2u * cx.per_axis + off + 2u * pkz);
+          const float2 tx2 = *reinterpret_cast<const float2*>(cx.tab - 2 + 2u * jx);
+          const float2 ty2 = *reinterpret_cast<const float2*>(cx.tab + cx.per_axis - 2 + 2u * jy);
+          const float2 tz2 = *reinterpret_cast<const float2*>(cx.tab + 2u * cx.per_axis - 2 + 2u * jz);
           cx0 = tx2.x; cx1 = tx2.y; cy0 = ty2.x; cy1 = ty2.y; cz0 = tz2.x; cz1 = tz2.y;
         } else {
           const double vs = res * (double)(1u << (D - lvl - 1));
+          const uint32_t pkx = jx - (1u << lvl), pky = jy - (1u << lvl), pkz = jz - (1u << lvl);
           cx0 = (float)(((double)(2u * pkx) + 0.5) * vs + omin[0]);
           cx1 = (float)(((double)(2u * pkx + 1u) + 0.5) * vs + omin[0]);
           cy0 = (float)(((double)(2u * pky) + 0.5) * vs + omin[1]);
@@ -191,9 +194,9 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
           if (!((mask >> ideal) & 1u)) dbg_hard++;
         }
         node = base + __popc(mask & ((1u << bc) - 1u));
-        pkx = 2u * pkx + ((bc >> 2) & 1u);
-        pky = 2u * pky + ((bc >> 1) & 1u);
-        pkz = 2u * pkz + (bc & 1u);
+        jx = 2u * jx + ((bc >> 2) & 1u);
+        jy = 2u * jy + ((bc >> 1) & 1u);
+        jz = 2u * jz + (bc & 1u);
       }
       // ---- leaf scan: first strictly-smaller wins (insertion order) ----
       uint32_t ls, le;
