@@ -118,29 +118,32 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
                       (tz < cx.ncell);
         const float fx = tx - flx, fy = ty - fly, fz = tz - flz;
         const float mg = cx.margin, mh = 1.0f - cx.margin;
-        const uint32_t lowf = (fx < mg ? 1u : 0u) | (fy < mg ? 2u : 0u) | (fz < mg ? 4u : 0u);
-        const uint32_t highf = (fx > mh ? 1u : 0u) | (fy > mh ? 2u : 0u) | (fz > mh ? 4u : 0u);
-        const bool risky = (lowf | highf) != 0u;
         const uint32_t kx = inside ? (uint32_t)flx : 0u, ky = inside ? (uint32_t)fly : 0u,
                        kz = inside ? (uint32_t)flz : 0u;
-        if (inside && cx.J > 0) {
+        // The shortcut may not be taken at a level whose cell has a face within the margin of the query.  The cell
+        // of 2^sh leaf cells has its low (high) face on an axis exactly at the query's leaf-cell face iff the low sh
+        // key bits are all 0 (all 1): the levels concerned are sh <= V, V = max over the axes that are within
+        // the margin of (trailing zeros | trailing ones) of the key.  Queries outside the box take no shortcut.
+        const int vx = fx < mg ? (kx ? __builtin_ctz(kx) : 31) : (fx > mh ? __builtin_ctz(~kx) : -1);
+        const int vy = fy < mg ? (ky ? __builtin_ctz(ky) : 31) : (fy > mh ? __builtin_ctz(~ky) : -1);
+        const int vz = fz < mg ? (kz ? __builtin_ctz(kz) : 31) : (fz > mh ? __builtin_ctz(~kz) : -1);
+        const int V = inside ? max(vx, max(vy, vz)) : 31;
+        const int lim = min(D, D - 1 - V);  // fast levels are those with lvl < lim
+        if (cx.J > 0 && cx.J <= lim) {  // the jump lands on level J: its cell spans 2^(D-J) leaf cells, D-J > V
           const int sh = D - cx.J;
-          if (!(risky && face_violation(kx, ky, kz, lowf, highf, sh))) {
-            const uint32_t e = cx.jump[(kx >> sh) | ((ky >> sh) << cx.J) | ((kz >> sh) << (2 * cx.J))];
-            if (e) {  // all ancestors of an existing node exist and contain the query
-              node = cx.lvlJ_start + e - 1u;
-              lvl = cx.J;
-              dbg_jump = 1;
-            }
+          const uint32_t e = cx.jump[(kx >> sh) | ((ky >> sh) << cx.J) | ((kz >> sh) << (2 * cx.J))];
+          if (e) {  // all ancestors of an existing node exist and contain the query
+            node = cx.lvlJ_start + e - 1u;
+            lvl = cx.J;
+            dbg_jump = 1;
           }
         }
         // fast levels: follow the key while the child containing the query exists
-        while (inside && lvl < D) {
+        while (lvl < lim) {
           const int sh = D - lvl - 1;
           const uint32_t c = (((kx >> sh) & 1u) << 2) | (((ky >> sh) & 1u) << 1) | ((kz >> sh) & 1u);
           const uint32_t wv = W[node];
           if (!((wv >> c) & 1u)) break;
-          if (risky && face_violation(kx, ky, kz, lowf, highf, sh)) break;
           node = (wv >> 8) + __popc(wv & 0xffu & ((1u << c) - 1u));
           lvl++;
           dbg_fast++;
