@@ -114,8 +114,9 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         const float tx = (qx - cx.ominx) * cx.inv_res, ty = (qy - cx.ominy) * cx.inv_res,
                     tz = (qz - cx.ominz) * cx.inv_res;
         const float flx = floorf(tx), fly = floorf(ty), flz = floorf(tz);
-        bool inside = (tx >= 0.0f) && (tx < cx.ncell) && (ty >= 0.0f) && (ty < cx.ncell) && (tz >= 0.0f) &&
-                      (tz < cx.ncell);
+        // (bitwise &: no short-circuit branches)
+        const bool inside = (tx >= 0.0f) & (tx < cx.ncell) & (ty >= 0.0f) & (ty < cx.ncell) & (tz >= 0.0f) &
+                            (tz < cx.ncell);
         const float fx = tx - flx, fy = ty - fly, fz = tz - flz;
         const float mg = cx.margin, mh = 1.0f - cx.margin;
         const uint32_t kx = inside ? (uint32_t)flx : 0u, ky = inside ? (uint32_t)fly : 0u,
@@ -129,16 +130,16 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         const int vz = fz < mg ? (kz ? __builtin_ctz(kz) : 31) : (fz > mh ? __builtin_ctz(~kz) : -1);
         const int V = inside ? max(vx, max(vy, vz)) : 31;
         const int lim = min(D, D - 1 - V);  // fast levels are those with lvl < lim
-        if (cx.J > 0 && cx.J <= lim) {  // the jump lands on level J: its cell spans 2^(D-J) leaf cells, D-J > V
+        if (cx.J > 0) {  // (wave-uniform) the jump lands on level J: its cell spans 2^(D-J) leaf cells, D-J > V
           const int sh = D - cx.J;
           const uint32_t e = cx.jump[(kx >> sh) | ((ky >> sh) << cx.J) | ((kz >> sh) << (2 * cx.J))];
-          if (e) {  // all ancestors of an existing node exist and contain the query
-            node = cx.lvlJ_start + e - 1u;
-            lvl = cx.J;
-            dbg_jump = 1;
-          }
+          const bool take = (cx.J <= lim) & (e != 0u);  // all ancestors of an existing node exist and contain the query
+          node = take ? cx.lvlJ_start + e - 1u : 0u;
+          lvl = take ? cx.J : 0;
+          if (DEBUG_NN) dbg_jump = take ? 1 : 0;
         }
-        // fast levels: follow the key while the child containing the query exists
+        // fast levels: follow the key while the child containing the query exists (a divergent loop: a version
+        // with a wave-uniform trip count and predicated steps was slower, 280 us against 267)
         while (lvl < lim) {
           const int sh = D - lvl - 1;
           const uint32_t c = (((kx >> sh) & 1u) << 2) | (((ky >> sh) & 1u) << 1) | ((kz >> sh) & 1u);
