@@ -215,26 +215,23 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
       if (abl & 2) le = ls;
       float bd = (abl & 2) ? 1.0e-3f : INFINITY;
       uint32_t bpos = ls;
-      float4 bt = make_float4(0, 0, 0, 0);
       for (uint32_t pos = ls; pos < le; pos += 2) {  // two candidates per round: their gathers overlap
         const bool two = pos + 1 < le;
         const float4 c = d.leaf_pts[pos];
         const float4 c2 = d.leaf_pts[two ? pos + 1 : pos];
         float dx = c.x - qx, dy = c.y - qy, dz = c.z - qz;
         float dd = dx * dx + (dy * dy + dz * dz);
-        if (dd < bd) {
-          bd = dd;
-          bpos = pos;
-          bt = c;
-        }
+        bool better = dd < bd;
+        bd = better ? dd : bd;
+        bpos = better ? pos : bpos;
         dx = c2.x - qx; dy = c2.y - qy; dz = c2.z - qz;
         dd = dx * dx + (dy * dy + dz * dz);
-        if (two && dd < bd) {
-          bd = dd;
-          bpos = pos + 1;
-          bt = c2;
-        }
+        better = two & (dd < bd);
+        bd = better ? dd : bd;
+        bpos = better ? pos + 1 : bpos;
       }
+      // the winner's record (position + packed colour) is fetched again instead of being carried through the loop
+      const float4 bt = d.leaf_pts[bpos];
       if (DEBUG_NN) {
         const size_t o = (size_t)pi * M + d.ref_perm[j];
         d.nn_idx[o] = (int32_t)d.leaf_order[bpos];
