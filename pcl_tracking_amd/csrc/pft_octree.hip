@@ -463,8 +463,8 @@ __global__ __launch_bounds__(PFT_BUILD_THREADS) void k_octree_build(PftParams pr
   if (n > 0 && !S.err) {
     if (n <= 4u * PFT_BUILD_THREADS) build_regs<4>(prm, d, S, n, lds_words, cap, lds_tmp, &leaf_start, &n_leaves, &path);
     else if (n <= 8u * PFT_BUILD_THREADS) build_regs<8>(prm, d, S, n, lds_words, cap, lds_tmp, &leaf_start, &n_leaves, &path);
-    // 12 points per thread is the last register-resident size without scratch (16 spills 12 VGPRs)
-    else if (n <= 12u * PFT_BUILD_THREADS) build_regs<12>(prm, d, S, n, lds_words, cap, lds_tmp, &leaf_start, &n_leaves, &path);
+    // 14 points per thread is the last register-resident size without scratch (126 VGPRs; 16 spills 12)
+    else if (n <= 14u * PFT_BUILD_THREADS) build_regs<14>(prm, d, S, n, lds_words, cap, lds_tmp, &leaf_start, &n_leaves, &path);
     else if (n <= 18u * PFT_BUILD_THREADS) build_hybrid<8>(prm, d, S, n, lds_words, cap, lds_tmp, &leaf_start, &n_leaves, &path);
     else build_tree_any<GlobStore>(prm, d, S, n, lds_words, cap, lds_tmp, &leaf_start, &n_leaves);
   }
