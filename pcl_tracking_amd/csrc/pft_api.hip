@@ -816,8 +816,14 @@ extern "C" int pft_get_particles(pft_tracker* t, pft_particle* out, size_t cap, 
 }
 
 extern "C" int pft_set_particles(pft_tracker* t, const pft_particle* p, size_t n) {
-  if (!t || !p || n != t->prm.P_local) return PFT_ERR_INVALID_ARG;
+  if (!t || !p) return PFT_ERR_INVALID_ARG;
+  if (t->prm.kld ? (n == 0 || n > t->Pcap) : (n != t->prm.P_local)) return PFT_ERR_INVALID_ARG;
   HIPCHK(t, hipMemcpyAsync(t->d_part[t->cur], p, n * sizeof(pft_particle), hipMemcpyHostToDevice, t->stream));
+  if (t->prm.kld) {  // particle_num_ of the KLD variant lives on the device
+    const uint32_t pa = (uint32_t)n;
+    HIPCHK(t, hipMemcpyAsync(&t->d_hdr->p_active, &pa, sizeof(pa), hipMemcpyHostToDevice, t->stream));
+    HIPCHK(t, hipStreamSynchronize(t->stream));
+  }
   pftk_pose_to_matrix(t->stream, t->d_part[t->cur], (uint32_t)n, t->d_mats);
   pft_particle rep;
   pft_to_state(t->trans, &rep);
@@ -854,7 +860,7 @@ extern "C" int pft_eval_weights(pft_tracker* t, const pft_particle* particles, s
   int r = check_ready(t);
   if (r != PFT_OK) return r;
   if (!particles || !P) return PFT_ERR_INVALID_ARG;
-  if (P > t->prm.P_local) return PFT_ERR_CAPACITY;
+  if (P > (t->prm.kld ? t->Pcap : t->prm.P_local)) return PFT_ERR_CAPACITY;
   r = ensure_dbg_part(t, P);
   if (r != PFT_OK) return r;
   r = ensure_dbg_f(t, P);
@@ -871,6 +877,7 @@ extern "C" int pft_eval_weights(pft_tracker* t, const pft_particle* particles, s
   }
   sync_dev(t);
   PftDev d = t->dev;
+  d.p_active = nullptr;  // explicit particle count (a KLD handle's device-side count does not apply here)
   d.part_cur = t->d_dbg_part;
   d.part_all = t->d_dbg_part;
   d.bbox6 = t->d_bbox6;
@@ -1001,6 +1008,7 @@ static int dbg_population(pft_tracker* t, std::vector<pft_particle>& host, int n
   HIPCHK(t, hipMemsetAsync(t->d_dbg_hdr, 0, sizeof(PftHeader), t->stream));
   sync_dev(t);
   PftDev d = t->dev;
+  d.p_active = nullptr;  // explicit particle count (a KLD handle's device-side count does not apply here)
   d.part_all = b.part;
   d.alias_list = b.list;
   d.alias_pref = b.pref;

@@ -94,3 +94,34 @@ def test_kld_tracker_rejects_sharding(gpu):
     t.setReferenceCloud(scene.make_model(64))
     with pytest.raises(PftError):
         t.setInputCloud(scene.make_model(64))
+
+
+def test_kld_handle_test_hooks_use_explicit_counts(gpu, orc):
+    """evalWeights / setParticles / the population hooks on a KLD handle take the caller's particle count, not the
+    device-side particle_num_ of the running filter"""
+    model, cloud = scene.make_model(1024), scene.make_scene(50000)
+    g = gpu.make_reference_tracker(particle_num=400, seed=4, kld=True)
+    g.setReferenceCloud(model)
+    g.setTrans(scene.initial_trans())
+    g.setInputCloud(cloud)
+    for _ in range(3):
+        g.compute()
+    n_run = len(g.getParticles())
+    o = orc.Tracker(orc.default_config(particle_num=300, threads=0, emulate_pcl_alloc=0))
+    o.set_reference(model)
+    o.set_trans(scene.initial_trans())
+    o.set_input(cloud)
+    p = population(300, 8, 0.02)
+    G = g.evalWeights(p)
+    O = o.eval_weights(p, mats=g.debugPoseToMatrix(p))
+    assert len(G["raw"]) == 300
+    np.testing.assert_array_equal(G["crop_idx"], O["crop_idx"])
+    d = np.abs(G["raw"].view(np.int32).astype(np.int64) - O["raw"].view(np.int32).astype(np.int64))
+    assert d.max() <= 1
+    w = np.random.default_rng(1).random(777).astype(np.float32)
+    got, _ = g.debugNormalize(-w * 100)
+    want, _ = orc.normalize_weights(-w * 100)
+    assert np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64)).max() <= 1
+    assert len(g.getParticles()) == n_run  # the running filter was not disturbed
+    g.setParticles(p[:123])
+    assert len(g.getParticles()) == 123
