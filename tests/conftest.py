@@ -23,6 +23,16 @@ def orc():
 
 
 @pytest.fixture(scope="session", autouse=True)
+def _native_library_is_built():
+    """the tests drive the in-tree HIP library: build it when it is missing or older than its sources (hipcc
+    cross-compiles gfx950 without a GPU; a no-op when pcl_tracking_amd/_build/libpft_hip.so is current)"""
+    from pcl_tracking_amd import build
+
+    build.build()
+    yield
+
+
+@pytest.fixture(scope="session", autouse=True)
 def _torch_hip_first():
     """PyTorch bundles its own HIP runtime; in a process that also uses torch on the GPU (test_gpu_dist,
     bench.py) torch has to initialise it before libpft_hip.so does.  No-op without a GPU."""
