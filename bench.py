@@ -144,7 +144,12 @@ def main():
     import numpy as np
     import torch
 
+    from pcl_tracking_amd import build as _hip_build
     from pcl_tracking_amd import scene
+
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        _hip_build.build()  # no-op when pcl_tracking_amd/_build/libpft_hip.so is current (it ships with the snapshot);
+        # multi-rank launches rely on the shipped library (no concurrent rebuild under the other ranks' feet)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
