@@ -93,7 +93,35 @@ def case_filters(name, w, h):
     print(name, len(frame), "->", len(idx), "->", len(approx512), len(approx64), len(exact))
 
 
+def case_kld(name):
+    """the KLD-adaptive resample: population + alias table in, new particle set / bins / k out"""
+    rng = np.random.default_rng(42)
+    gt = scene.model_gt_pose()
+    old = np.zeros(220, scene.PARTICLE_DTYPE)
+    for k, nm in enumerate(("x", "y", "z", "roll", "pitch", "yaw")):
+        old[nm] = gt[k] + rng.normal(0, 0.004, len(old))  # tight population: the KL bound stops the loop early
+    old["w"] = 1.0
+    w = rng.random(len(old)).astype(np.float32) ** 3
+    old["weight"] = w / w.sum()
+    a, q = orc.gen_alias_table(old["weight"])
+    motion = np.zeros(1, scene.PARTICLE_DTYPE)
+    motion["x"], motion["pitch"] = 0.003, 0.01
+    cfg = orc.default_config(kld_adaptive=1, seed=21)
+    out = {}
+    for epoch in (0, 5):
+        p, bins, k = orc.kld_resample(cfg, old, a, q, motion, epoch)
+        out["particles_%d" % epoch] = p.view(np.float32).reshape(-1, 8)
+        out["bins_%d" % epoch] = bins
+        out["k_%d" % epoch] = k
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), old=old.view(np.float32).reshape(-1, 8), alias_a=a, alias_q=q,
+                        motion=motion.view(np.float32).reshape(-1, 8), seed=21, **out)
+    print(name, [len(out["particles_%d" % e]) for e in (0, 5)], [out["k_%d" % e] for e in (0, 5)])
+
+
 if __name__ == "__main__":
+    if "kld" in sys.argv[1:]:
+        case_kld("kld_small")
+        sys.exit(0)
     if "filters" in sys.argv[1:]:  # only the front-end fixture (leaves the tracker fixtures untouched)
         case_filters("filters_small", 96, 54)
         sys.exit(0)

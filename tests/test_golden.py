@@ -142,3 +142,37 @@ def test_hip_reproduces_filter_fixture():
     g.setLeafSize(d["leaf"])
     g.setInputCloud(d["frame"][d["pass_idx"]])
     assert g.filter().tobytes() == d["exact"].tobytes()
+
+
+# ---- KLD-adaptive resample: tests/golden/kld_small.npz ----
+def load_kld():
+    z = np.load(os.path.join(G, "kld_small.npz"))
+    d = {k: z[k] for k in z.files}
+    for k in ("old", "motion", "particles_0", "particles_5"):
+        d[k] = np.ascontiguousarray(d[k]).view(scene.PARTICLE_DTYPE).reshape(-1)
+    return d
+
+
+def test_oracle_reproduces_kld_fixture(orc):
+    d = load_kld()
+    cfg = orc.default_config(kld_adaptive=1, seed=int(d["seed"]))
+    for epoch in (0, 5):
+        p, bins, k = orc.kld_resample(cfg, d["old"], d["alias_a"], d["alias_q"], d["motion"], epoch)
+        assert p.tobytes() == d["particles_%d" % epoch].tobytes()
+        np.testing.assert_array_equal(bins, d["bins_%d" % epoch])
+        assert k == int(d["k_%d" % epoch])
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_kld_fixture():
+    from pcl_tracking_amd import tracker
+
+    d = load_kld()
+    g = tracker.make_reference_tracker(particle_num=len(d["old"]), seed=int(d["seed"]), kld=True)
+    for epoch in (0, 5):
+        p, bins, k = g.debugKldResample(d["old"], d["alias_a"], d["alias_q"], d["motion"], epoch)
+        want = d["particles_%d" % epoch]
+        assert len(p) == len(want) and k == int(d["k_%d" % epoch])
+        np.testing.assert_array_equal(bins, d["bins_%d" % epoch])
+        for c in KEYS:  # Box-Muller's log / sin / cos in double: ocml against glibc
+            assert np.abs(p[c] - want[c]).max() <= 1e-6
