@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PFT_ABI_VERSION 2
+#define PFT_ABI_VERSION 3
 
 /* pcl::PointXYZRGBA (32 B, 16-aligned): x,y,z,1.0f | rgba (bytes b,g,r,a) | 12 B pad */
 typedef struct pft_point_xyzrgba {
@@ -87,6 +87,9 @@ typedef struct pft_config {
   double kld_epsilon;            /* setEpsilon            :211   0.2 */
   double kld_bin_size[6];        /* setBinSize            :212-219  0.1 each */
   double motion_ratio;           /* ParticleFilterTracker ctor default 0.25 (used by the KLD resample only) */
+  /* NearestPairPointCloudCoherence (true nearest neighbour) instead of ApproxNearestPair...: the alternative the
+   * reference keeps commented out at auto_tracking.cpp:237-238, :249 */
+  int32_t exact_nearest;
 } pft_config;
 
 typedef struct pft_tracker pft_tracker;

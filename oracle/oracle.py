@@ -33,6 +33,7 @@ class Config(C.Structure):
         ("seed", C.c_uint64),
         ("kld_adaptive", C.c_int32), ("kld_max_particles", C.c_int32), ("kld_delta", C.c_double),
         ("kld_epsilon", C.c_double), ("kld_bin_size", C.c_double * 6), ("motion_ratio", C.c_double),
+        ("exact_nearest", C.c_int32),
     ]
 
 

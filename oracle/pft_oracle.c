@@ -55,6 +55,7 @@ void orc_config_default(orc_config_t* c) {
   c->kld_epsilon = 0.2;       /* :211 */
   for (int k = 0; k < 6; k++) c->kld_bin_size[k] = 0.1; /* :212-219 */
   c->motion_ratio = 0.25;
+  c->exact_nearest = 0;
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -882,7 +883,10 @@ size_t orc_tracker_eval_weights(orc_tracker_t* t, const orc_particle_t* particle
     for (size_t i = 0; i < nc && i < crop_cap; i++) crop_idx[i] = iz[i];
   double t2 = omp_get_wtime();
   /* A5: coherence_->setTargetCloud(cropped); initCompute() -> search::Octree(0.01).setInputCloud */
-  orc_octree_t* tree = orc_octree_build(cz, nc, t->cfg.octree_resolution, t->cfg.emulate_pcl_alloc);
+  /* (NearestPairPointCloudCoherence, cfg.exact_nearest: the search structure is irrelevant to the result; the true
+   * nearest neighbour is found by exhaustive search below) */
+  const int exact = t->cfg.exact_nearest;
+  orc_octree_t* tree = orc_octree_build(cz, exact ? 0 : nc, t->cfg.octree_resolution, t->cfg.emulate_pcl_alloc);
   if (octree_depth || octree_bounds) orc_octree_info(tree, octree_depth, octree_bounds, NULL, NULL);
   double t3 = omp_get_wtime();
   /* A7: ApproxNearestPairPointCloudCoherence::computeCoherence per particle (OMP loop 2) */
@@ -896,7 +900,23 @@ size_t orc_tracker_eval_weights(orc_tracker_t* t, const orc_particle_t* particle
       int k_index = 0;
       float k_distance = 0.0f;
       orc_point_t input_point = cloud[j];
-      int scanned = orc_octree_approx_nearest(tree, &input_point, &k_index, &k_distance);
+      int scanned;
+      if (exact) {
+        /* NearestPairPointCloudCoherence::computeCoherence (tracking/impl/nearest_pair_point_cloud_coherence.hpp):
+         * search_->nearestKSearch(input_point, 1, ...): the nearest target point, squared distance in float
+         * (pointSquaredDist); equal distances: the lowest index (upstream leaves the order of ties to std::sort) */
+        scanned = (int)nc;
+        k_distance = INFINITY;
+        for (size_t c = 0; c < nc; c++) {
+          const float dd = point_sq_dist(cz[c].x, cz[c].y, cz[c].z, input_point.x, input_point.y, input_point.z);
+          if (dd < k_distance) {
+            k_distance = dd;
+            k_index = (int)c;
+          }
+        }
+      } else {
+        scanned = orc_octree_approx_nearest(tree, &input_point, &k_index, &k_distance);
+      }
       if (!scanned) { /* empty target: PCL asserts (UB in release); defined here as "no correspondence" */
         if (nn_idx) nn_idx[(size_t)i * M + j] = -1;
         if (nn_d2) nn_d2[(size_t)i * M + j] = INFINITY;

@@ -63,6 +63,9 @@ typedef struct {
   double kld_epsilon;        /* :211  0.2 */
   double kld_bin_size[6];    /* :212-219  0.1 each (stored as the float members of a ParticleXYZRPY upstream) */
   double motion_ratio;       /* PCL particle_filter.h ctor: 0.25 */
+  /* NearestPairPointCloudCoherence instead of the Approx... one: the alternative left commented out at
+   * /root/reference/src/auto_tracking.cpp:237-238: true nearest neighbour in the cropped cloud */
+  int32_t exact_nearest;
 } orc_config_t;
 
 void orc_config_default(orc_config_t* c);

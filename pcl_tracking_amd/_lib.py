@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libpft_hip.so")
 
-PFT_ABI_VERSION = 2
+PFT_ABI_VERSION = 3
 K_RESAMPLE, K_AABB, K_CROP, K_OCTREE, K_LIKELIHOOD, K_POPULATION, K_PACK, K_COUNT = range(8)
 
 STATUS = {0: "ok", 1: "invalid argument", 2: "no input cloud", 3: "no reference cloud", 4: "no usable HIP device",
@@ -34,6 +34,7 @@ class Config(C.Structure):
         ("max_reference_points", C.c_uint32), ("max_input_points", C.c_uint32),
         ("kld_adaptive", C.c_int32), ("maximum_particle_num", C.c_int32), ("kld_delta", C.c_double),
         ("kld_epsilon", C.c_double), ("kld_bin_size", C.c_double * 6), ("motion_ratio", C.c_double),
+        ("exact_nearest", C.c_int32),
     ]
 
 

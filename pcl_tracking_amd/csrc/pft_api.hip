@@ -66,6 +66,7 @@ struct pft_tracker {
   int32_t* d_alias_list = nullptr;
   double* d_alias_pref = nullptr;
   double* d_pop_part = nullptr;
+  uint32_t *d_eg_start = nullptr, *d_eg_cnt = nullptr, *d_eg_tile = nullptr;
   uint32_t* d_kld_table = nullptr;
   int32_t* d_kld_bins = nullptr;
   uint32_t dbg_builds = 0;
@@ -151,6 +152,7 @@ extern "C" void pft_config_default(pft_config* c) {
   c->kld_epsilon = 0.2;           // :211
   for (int k = 0; k < 6; k++) c->kld_bin_size[k] = 0.1;  // :212-219
   c->motion_ratio = 0.25;
+  c->exact_nearest = 0;  // ApproxNearestPairPointCloudCoherence, as the reference runs (:235-236)
 }
 
 // KLDAdaptiveParticleFilterTracker::normalQuantile (kld_adaptive_particle_filter.h): despite its name the polynomial
@@ -313,6 +315,10 @@ static void sync_dev(pft_tracker* t) {
   d.alias_pref = t->d_alias_pref;
   d.pop_part = t->d_pop_part;
   d.p_active = t->prm.kld ? &t->d_hdr->p_active : nullptr;
+  d.eg_start = t->d_eg_start;
+  d.eg_cnt = t->d_eg_cnt;
+  d.eg_tile = t->d_eg_tile;
+  d.eg_cap = t->d_eg_start ? PFT_EG_CAP : 0u;
   d.kld_table = t->d_kld_table;
   d.kld_bins = t->d_kld_bins;
   d.alias_pos = t->d_alias_pos;
@@ -440,6 +446,11 @@ extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
   A(dalloc(&t->d_alias_pref, 2 * Pt));
   A(dalloc(&t->d_pop_part, (size_t)PFT_POPM_MAX_WGS * 16));
   A(dalloc(&t->d_alias_pos, Pt));
+  if (cfg->exact_nearest) {
+    A(dalloc(&t->d_eg_start, (size_t)PFT_EG_CAP + 1));
+    A(dalloc(&t->d_eg_cnt, (size_t)PFT_EG_CAP));
+    A(dalloc(&t->d_eg_tile, (size_t)PFT_EG_CAP / 2048 + 2));
+  }
   if (p.kld) {
     A(dalloc(&t->d_kld_table, (size_t)6 * p.kld_max + 128));
     A(dalloc(&t->d_kld_bins, (size_t)6 * p.kld_max));
@@ -490,7 +501,7 @@ extern "C" void pft_destroy(pft_tracker* t) {
   dfree(t->d_pt_key64); dfree(t->sort.keys[0]); dfree(t->sort.keys[1]); dfree(t->sort.vals[0]); dfree(t->sort.vals[1]);
   dfree(t->sort.hist); dfree(t->sort.tile_cnt); dfree(t->sort.tile_box); if (t->h_stat) hipHostFree(t->h_stat);
   dfree(t->d_partial); dfree(t->d_alias_list); dfree(t->d_alias_pos);
-  dfree(t->d_alias_pref); dfree(t->d_pop_part); dfree(t->d_kld_table); dfree(t->d_kld_bins); dfree(t->d_hdr); dfree(t->d_nn_idx); dfree(t->d_nn_d2); dfree(t->d_dbg_part);
+  dfree(t->d_alias_pref); dfree(t->d_pop_part); dfree(t->d_kld_table); dfree(t->d_kld_bins); dfree(t->d_eg_start); dfree(t->d_eg_cnt); dfree(t->d_eg_tile); dfree(t->d_hdr); dfree(t->d_nn_idx); dfree(t->d_nn_d2); dfree(t->d_dbg_part);
   dfree(t->d_dbg_hdr); dfree(t->d_dbg_f);
   if (t->own_stream && t->stream) hipStreamDestroy(t->stream);
   delete t;
@@ -648,6 +659,15 @@ static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32
   {
     ProfScope ps(t, PFT_K_CROP);
     pftk_crop(t->stream, t->prm, d, bbox_from_partials);
+  }
+  if (t->cfg.exact_nearest) {  // NearestPairPointCloudCoherence: uniform grid + true nearest neighbour, no octree
+    {
+      ProfScope ps(t, PFT_K_OCTREE);
+      pftk_exact_grid(t->stream, t->prm, d);
+    }
+    ProfScope ps(t, PFT_K_LIKELIHOOD);
+    pftk_likelihood_exact(t->stream, t->prm, d, np, debug_nn, t->num_cus);
+    return;
   }
   {
     ProfScope ps(t, PFT_K_OCTREE);

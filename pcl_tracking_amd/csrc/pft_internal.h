@@ -33,6 +33,7 @@
 #endif
 #define PFT_POP_THREADS 1024
 #define PFT_SORTED_BUILD_MIN 18000  // cropped points (last iteration) above which the sorted builder is used
+#define PFT_EG_CAP (1u << 21)     // exact-NN mode: grid cells (8 MB of cell starts)
 #define PFT_POPM_THREADS 256
 #define PFT_POPM_ITEMS 16   // many-workgroup population path: 4096 particles per workgroup
 #define PFT_POPM_MAX_WGS 256
@@ -86,6 +87,10 @@ struct PftHeader {  // lives in HBM; written by kernels, read by later kernels (
   pft_particle rep;
   pft_particle motion;
   uint32_t alias_m, alias_nh;   // sizes of the small / large lists
+  // exact-nearest-neighbour mode (pft_exact_nn.hip): uniform grid over the crop box
+  float eg_g, eg_inv_g, eg_min[3];
+  int32_t eg_dim[3];
+  uint32_t eg_ncells;
   uint32_t p_active;            // KLD variant: current particle_num_ (written by init / k_resample_kld)
   uint32_t kld_k;               // KLD variant: distinct bins of the last resample (diagnostic)
   unsigned long long stat_queries, stat_scanned;
@@ -125,6 +130,10 @@ struct PftDev {  // device pointers (host-side struct, passed by value)
   double* pop_part;      // [PFT_POPM_MAX_WGS][16] per-workgroup partials of the many-workgroup population path
   PftHeader* hdr;
   const uint32_t* p_active;  // KLD variant: &hdr->p_active (kernels take the particle count from here), else null
+  uint32_t* eg_start;        // exact-NN mode: [eg_cap + 1] first slot of every grid cell
+  uint32_t* eg_cnt;          // exact-NN mode: [eg_cap] cell counts / fill cursors
+  uint32_t* eg_tile;         // exact-NN mode: per-2048-cell tile sums
+  uint32_t eg_cap;           // exact-NN mode: cells available
   uint32_t* kld_table;       // KLD variant: open-addressing table of first occurrences, 2 x pow2(kld_max) entries
   int32_t* kld_bins;         // KLD variant: 6 ints per candidate
   uint32_t* host_stat;  // pinned host memory, device-visible: [0] last n_crop, [1] last octree depth (read by the
@@ -145,6 +154,10 @@ void pftk_resample_table(hipStream_t s, const PftParams& p, const pft_particle* 
                          const double* q, const PftHeader* hdr, uint32_t epoch, pft_particle* out);
 void pftk_pose_to_matrix(hipStream_t s, const pft_particle* p, uint32_t n, float* mats);
 void pftk_aabb(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, bool finalize);
+// NearestPairPointCloudCoherence mode: uniform grid over the cropped cloud, then the likelihood with the true NN
+void pftk_exact_grid(hipStream_t s, const PftParams& p, const PftDev& d);
+void pftk_likelihood_exact(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, bool debug_nn,
+                           int num_cus);
 // KLD variant: draws up to p.kld_max candidates from d.part_all[0 .. p_active) (alias prefix form, or the explicit
 // table a/q when given), keeps the prefix the KL bound asks for, writes particles + matrices and the new p_active
 void pftk_resample_kld(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t epoch, pft_particle* out,

@@ -141,6 +141,8 @@ class ApproxNearestPairPointCloudCoherence {
   typedef std::shared_ptr<ApproxNearestPairPointCloudCoherence<PointInT>> Ptr;
   typedef std::shared_ptr<PointCoherence<PointInT>> PointCoherencePtr;
   ApproxNearestPairPointCloudCoherence() : maximum_distance_(1e30), resolution_(0.01) {}
+  virtual ~ApproxNearestPairPointCloudCoherence() {}
+  virtual bool exactNearest() const { return false; }
   void addPointCoherence(const PointCoherencePtr& c) { point_coherences_.push_back(c); }
   // upstream keeps its own search::Octree(0.01) and ignores the object passed here; the reference passes
   // the same 0.01 (auto_tracking.cpp:250), so the resolution is taken from it
@@ -155,6 +157,14 @@ class ApproxNearestPairPointCloudCoherence {
  private:
   std::vector<PointCoherencePtr> point_coherences_;
   double maximum_distance_, resolution_;
+};
+
+// pcl::tracking::NearestPairPointCloudCoherence: the true nearest neighbour instead of the greedy octree descent
+// (the alternative auto_tracking.cpp keeps commented out at :237-238, :249); same setters
+template <typename PointInT>
+class NearestPairPointCloudCoherence : public ApproxNearestPairPointCloudCoherence<PointInT> {
+ public:
+  bool exactNearest() const override { return true; }
 };
 
 template <typename PointInT, typename StateT>
@@ -198,6 +208,7 @@ class ParticleFilterTracker {
     coherence_ = c;
     cfg_.max_distance = c->getMaximumDistance();
     cfg_.octree_resolution = c->getResolution();
+    cfg_.exact_nearest = c->exactNearest() ? 1 : 0;
     const auto& pcs = c->getPointCoherences();
     if (pcs.size() != 2 || pcs[0]->kind() != PointCoherence<PointInT>::DISTANCE ||
         pcs[1]->kind() != PointCoherence<PointInT>::HSV)

@@ -71,6 +71,12 @@ class ApproxNearestPairPointCloudCoherence:
         self.maximum_distance = float(d)
 
 
+class NearestPairPointCloudCoherence(ApproxNearestPairPointCloudCoherence):
+    """pcl::tracking::NearestPairPointCloudCoherence: the true nearest neighbour instead of the greedy octree
+    descent -- the alternative auto_tracking.cpp keeps commented out (:237-238, :249)"""
+    exact = True
+
+
 class ParticleFilterTracker:
     """pcl::tracking::ParticleFilterOMPTracker<PointXYZRGBA, ParticleXYZRPY>, fixed particle number."""
 
@@ -142,6 +148,7 @@ class ParticleFilterTracker:
         self._cfg_guard()
         self._cfg.max_distance = coh.maximum_distance
         self._cfg.octree_resolution = coh.resolution
+        self._cfg.exact_nearest = 1 if getattr(coh, "exact", False) else 0
         kinds = [type(c) for c in coh.point_coherences]
         if kinds != [DistanceCoherence, HSVColorCoherence]:
             raise PftError(1, "supported point coherences: DistanceCoherence then HSVColorCoherence "

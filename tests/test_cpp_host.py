@@ -30,7 +30,7 @@ def test_cpp_mirror_uses_the_reference_call_names():
                  "compute", "addPointCoherence", "setWeight", "setSearchMethod", "setMaximumDistance",
                  "ParticleFilterOMPTracker", "ApproxNearestPairPointCloudCoherence", "DistanceCoherence",
                  "HSVColorCoherence", "KLDAdaptiveParticleFilterOMPTracker", "setMaximumParticleNum", "setDelta",
-                 "setEpsilon", "setBinSize"):
+                 "setEpsilon", "setBinSize", "NearestPairPointCloudCoherence"):
         assert name in hdr, name
     # the filter classes of cloud_cb's front end (auto_tracking.cpp:536-575)
     fh = open(os.path.join(root, "pcl_tracking_amd", "include", "pft", "filters.hpp")).read()

@@ -439,3 +439,53 @@ def test_compute_other_iteration_counts(gpu, orc, data, iters):
         rg, ro = g.getResult(), o.get_result()
         for k in ("x", "y", "z", "roll", "pitch", "yaw"):
             assert abs(float(rg[k]) - float(ro[k])) < 1e-4, (f, k)
+
+
+# ---- NearestPairPointCloudCoherence (true nearest neighbour) -----------------------------------
+@pytest.mark.parametrize("M,N,P,maxd", [(256, 6000, 48, 0.1), (513, 20000, 33, 0.1), (64, 900, 20, 0.03), (300, 50000, 16, 0.25)])
+def test_exact_nearest_pair_coherence(gpu, orc, data, M, N, P, maxd):
+    model = scene.make_model(M, seed=900 + M)
+    cloud = data["scene"][:N]
+    o = orc.Tracker(orc.default_config(particle_num=P, threads=0, emulate_pcl_alloc=0, exact_nearest=1, max_distance=maxd))
+    g = gpu.ParticleFilterTracker(seed=1)
+    g.setParticleNum(P)
+    coh = gpu.NearestPairPointCloudCoherence()
+    coh.addPointCoherence(gpu.DistanceCoherence())
+    hc = gpu.HSVColorCoherence()
+    hc.setWeight(0.1)
+    coh.addPointCoherence(hc)
+    coh.setSearchMethod(gpu.OctreeSearch(0.01))
+    coh.setMaximumDistance(maxd)
+    g.setCloudCoherence(coh)
+    for ref, tr, inp in ((g.setReferenceCloud, g.setTrans, g.setInputCloud), (o.set_reference, o.set_trans, o.set_input)):
+        ref(model)
+        tr(scene.initial_trans())
+        inp(cloud)
+    p = particles_around(data["gt"], P, 31 + M)
+    G = g.evalWeights(p, want_nn=True)
+    O = o.eval_weights(p, want_nn=True, mats=g.debugPoseToMatrix(p))
+    np.testing.assert_array_equal(G["crop_idx"], O["crop_idx"])
+    # inside the gate: the same neighbour (index and float squared distance); outside: the GPU does not search
+    gate = O["nn_d2"].astype(np.float64) < maxd * maxd
+    assert gate.any()
+    np.testing.assert_array_equal(G["nn_idx"][gate], O["nn_idx"][gate])
+    np.testing.assert_array_equal(G["nn_d2"][gate], O["nn_d2"][gate])
+    assert (G["nn_idx"][~gate] == -1).all()
+    d = ulp_diff(G["raw"], O["raw"])
+    assert d.max() <= 1, d.max()
+    # and a short tracking run in this mode
+    g2 = gpu.ParticleFilterTracker(seed=5)
+    g2.setParticleNum(200)
+    g2.setCloudCoherence(coh)
+    o2 = orc.Tracker(orc.default_config(particle_num=200, seed=5, threads=0, emulate_pcl_alloc=0, exact_nearest=1,
+                                        max_distance=maxd))
+    for ref, tr, inp in ((g2.setReferenceCloud, g2.setTrans, g2.setInputCloud), (o2.set_reference, o2.set_trans, o2.set_input)):
+        ref(model)
+        tr(scene.initial_trans())
+        inp(cloud)
+    for f in range(2):
+        g2.compute()
+        assert o2.compute() == 0
+        rg, ro = g2.getResult(), o2.get_result()
+        for k in ("x", "y", "z", "roll", "pitch", "yaw"):
+            assert abs(float(rg[k]) - float(ro[k])) < 1e-4, (f, k)

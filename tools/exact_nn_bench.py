@@ -1,0 +1,39 @@
+"""Frame time of the NearestPairPointCloudCoherence mode (true nearest neighbour) beside the approximate one.
+usage: python tools/exact_nn_bench.py [P]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pcl_tracking_amd import scene, tracker  # noqa: E402
+
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+model, cloud = scene.make_model(2048), scene.make_scene(50000)
+for exact in (False, True):
+    t = tracker.ParticleFilterTracker(seed=1)
+    t.setParticleNum(P)
+    coh = tracker.NearestPairPointCloudCoherence() if exact else tracker.ApproxNearestPairPointCloudCoherence()
+    coh.addPointCoherence(tracker.DistanceCoherence())
+    hc = tracker.HSVColorCoherence()
+    hc.setWeight(0.1)
+    coh.addPointCoherence(hc)
+    coh.setSearchMethod(tracker.OctreeSearch(0.01))
+    coh.setMaximumDistance(0.1)
+    t.setCloudCoherence(coh)
+    t.setReferenceCloud(model)
+    t.setTrans(scene.initial_trans())
+    t.setInputCloud(cloud)
+    for _ in range(10):
+        t.compute()
+    t.synchronize()
+    t.profileEnable(True)
+    t.profileReset()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        t.compute()
+    t.synchronize()
+    dt = (time.perf_counter() - t0) / 50
+    pr = t.profileGet()
+    print("%s: %.3f ms/frame (with events)  grid/octree %.1f us  likelihood %.1f us per launch" % (
+        "exact NN " if exact else "approx NN", dt * 1e3, pr["octree"][0] / pr["octree"][1] * 1e3,
+        pr["likelihood"][0] / pr["likelihood"][1] * 1e3))
