@@ -489,3 +489,36 @@ def test_exact_nearest_pair_coherence(gpu, orc, data, M, N, P, maxd):
         rg, ro = g2.getResult(), o2.get_result()
         for k in ("x", "y", "z", "roll", "pitch", "yaw"):
             assert abs(float(rg[k]) - float(ro[k])) < 1e-4, (f, k)
+
+
+def test_exact_nearest_edge_cases(gpu, orc, data):
+    """empty crop (no input point inside the particles' box) and a gate wider than the crop box"""
+    def pair(maxd, cloud, P=8):
+        o = orc.Tracker(orc.default_config(particle_num=P, threads=0, emulate_pcl_alloc=0, exact_nearest=1, max_distance=maxd))
+        g = gpu.ParticleFilterTracker(seed=1)
+        g.setParticleNum(P)
+        coh = gpu.NearestPairPointCloudCoherence()
+        coh.addPointCoherence(gpu.DistanceCoherence())
+        hc = gpu.HSVColorCoherence()
+        hc.setWeight(0.1)  # auto_tracking.cpp:246 (the class default is 1.0, the oracle's config default 0.1)
+        coh.addPointCoherence(hc)
+        coh.setMaximumDistance(maxd)
+        g.setCloudCoherence(coh)
+        for ref, tr, inp in ((g.setReferenceCloud, g.setTrans, g.setInputCloud), (o.set_reference, o.set_trans, o.set_input)):
+            ref(data["model"][:128])
+            tr(scene.initial_trans())
+            inp(cloud)
+        return g, o
+
+    far = data["scene"][:2000].copy()
+    far["z"] += 50.0  # nothing inside the crop box
+    g, o = pair(0.1, far)
+    p = particles_around(data["gt"], 8, 3)
+    G, O = g.evalWeights(p, want_nn=True), o.eval_weights(p, want_nn=True, mats=g.debugPoseToMatrix(p))
+    assert len(G["crop_idx"]) == 0 == len(O["crop_idx"])
+    assert (G["raw"] == 0).all() and (O["raw"] == 0).all() and (G["nn_idx"] == -1).all()
+    g, o = pair(2.0, data["scene"][:5000])  # every cropped point is inside the gate of every query
+    G, O = g.evalWeights(p, want_nn=True), o.eval_weights(p, want_nn=True, mats=g.debugPoseToMatrix(p))
+    np.testing.assert_array_equal(G["nn_idx"], O["nn_idx"])
+    np.testing.assert_array_equal(G["nn_d2"], O["nn_d2"])
+    assert ulp_diff(G["raw"], O["raw"]).max() <= 1
