@@ -1,5 +1,5 @@
 """Host logic of the particle-sharded path (pcl_tracking_amd/dist.py ShardedFilter) under gloo on CPU,
-world_size 2: sharding by global particle id, the MAX all-reduce of the AABB, the all-gather of
+world_size 2 and 4: sharding by global particle id, the MAX all-reduce of the AABB, the all-gather of
 (particle, raw weight) shards in rank order, RNG keyed by global id.
 
 There is no GPU here, so the per-rank stages are played by a stand-in built from the oracle's stage
@@ -117,15 +117,16 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-def test_two_ranks_reproduce_the_single_process_tracker(tmp_path, orc):
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_reproduce_the_single_process_tracker(tmp_path, orc, world):
     from pcl_tracking_amd import scene
 
-    P, frames, world = 64, 3, 2
+    P, frames = 64, 3
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), P, frames), nprocs=world, join=True)
     r0 = np.load(tmp_path / "res0.npy")
-    r1 = np.load(tmp_path / "res1.npy")
-    np.testing.assert_array_equal(r0, r1)  # replicated population stages agree on every rank
-    np.testing.assert_array_equal(np.load(tmp_path / "part0.npy"), np.load(tmp_path / "part1.npy"))
+    for r in range(1, world):  # replicated population stages agree on every rank
+        np.testing.assert_array_equal(r0, np.load(tmp_path / ("res%d.npy" % r)))
+        np.testing.assert_array_equal(np.load(tmp_path / "part0.npy"), np.load(tmp_path / ("part%d.npy" % r)))
     # single process, same seed
     model = scene.make_model(256)
     cloud = scene.make_scene(50000)[:6000]
