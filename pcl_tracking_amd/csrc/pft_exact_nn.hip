@@ -5,9 +5,9 @@
 // point coherences as the approximate variant.
 //
 // Only neighbours inside the gate contribute, so the search structure is a uniform grid over the crop box with a cell
-// of four octree leaves (4 cm): counting sort of the cropped points by cell (three small kernels per iteration), then
-// per query cubes of growing radius (in cells) around the query's cell are scanned, row by row, until the cube's
-// reach exceeds the best distance found (or the gate).  Nearest = smallest float distance, equal distances -> lowest index
+// of two octree leaves (2 cm): counting sort of the cropped points by cell (three small kernels per iteration), then
+// per query shells of growing radius (in cells) around the query's cell are scanned, row segment by row segment,
+// with rows farther than the best distance skipped, until the reach exceeds the best distance found (or the gate).  Nearest = smallest float distance, equal distances -> lowest index
 // (upstream leaves ties to std::sort).  No octree is built in this mode.
 #include "pft_device_utils.h"
 
@@ -22,7 +22,7 @@ __device__ __forceinline__ int eg_cell1(float v, float mn, float inv_g, int dim)
 __global__ void k_eg_setup(PftParams prm, PftDev d) {
   PftHeader* h = d.hdr;
   const uint32_t n = h->n_crop;
-  float g = (float)(4.0 * prm.res);
+  float g = (float)(2.0 * prm.res);
   int dim[3] = {1, 1, 1};
   if (n > 0) {
     for (;;) {
@@ -184,15 +184,39 @@ __global__ __launch_bounds__(256) void k_likelihood_exact(PftParams prm, PftDev 
         // the query's own cell (not clamped: a query outside the box starts its rings outside)
         const int cqx = (int)floorf((qx - mnx) * inv_g), cqy = (int)floorf((qy - mny) * inv_g),
                   cqz = (int)floorf((qz - mnz) * inv_g);
-        // cubes of growing radius around the query's cell: the cube of radius rr cells holds every point closer than
-        // rr * g, and the cells of one (z, y) row are contiguous in the sorted order, so a row costs two loads of cell
-        // starts however many cells it spans.  A larger cube rescans the smaller one (the minimum is idempotent).
-        for (int rr = 1; rr <= R; rr++) {
-          const int x0 = max(cqx - rr, 0), x1 = min(cqx + rr, dx_ - 1);
-          if (x0 <= x1) {
-            for (int cz = max(cqz - rr, 0); cz <= min(cqz + rr, dz_ - 1); cz++) {
-              for (int cy = max(cqy - rr, 0); cy <= min(cqy + rr, dy_ - 1); cy++) {
-                const uint32_t row = (uint32_t)((cz * dy_ + cy) * dx_);
+        // Shells of growing Chebyshev radius rr around the query's cell.  The cells of one (z, y) row are contiguous
+        // in the sorted order, so a row segment costs two loads of cell starts however many cells it spans: rows on the
+        // shell's faces are scanned over their whole x range, inner rows only at their two end cells.  A row whose
+        // cells are all farther than the best distance so far is skipped before anything is loaded (a point in a row
+        // at offset o is at least (|o| - 1) cells away on that axis), and once shell rr is done everything closer than
+        // rr * g has been seen.
+        const float gg = g * 0.9999f;
+        for (int rr = 0; rr <= R; rr++) {
+          for (int oz = -rr; oz <= rr; oz++) {
+            const int cz = cqz + oz;
+            if (cz < 0 || cz >= dz_) continue;
+            const float lz = (float)max(abs(oz) - 1, 0) * gg;
+            for (int oy = -rr; oy <= rr; oy++) {
+              const int cy = cqy + oy;
+              if (cy < 0 || cy >= dy_) continue;
+              const float ly = (float)max(abs(oy) - 1, 0) * gg;
+              const float lyz = ly * ly + lz * lz;
+              const bool face = (abs(oz) == rr) || (abs(oy) == rr);
+              const float lx = face ? 0.0f : (float)max(rr - 1, 0) * gg;
+              if (lyz + lx * lx > fminf(best, gate_f)) continue;
+              const uint32_t row = (uint32_t)((cz * dy_ + cy) * dx_);
+              // face rows: one segment [cqx-rr, cqx+rr]; inner rows: the two cells cqx-rr and cqx+rr
+              const int nseg = (face || rr == 0) ? 1 : 2;
+              for (int sgi = 0; sgi < nseg; sgi++) {
+                int x0, x1;
+                if (nseg == 1) {
+                  x0 = max(cqx - rr, 0);
+                  x1 = min(cqx + rr, dx_ - 1);
+                } else {
+                  x0 = x1 = sgi == 0 ? cqx - rr : cqx + rr;
+                  if (x0 < 0 || x0 >= dx_) continue;
+                }
+                if (x0 > x1) continue;
                 const uint32_t s0 = d.eg_start[row + (uint32_t)x0], s1 = d.eg_start[row + (uint32_t)x1 + 1u];
                 for (uint32_t pos = s0; pos < s1; pos++) {
                   const float4 p = d.leaf_pts[pos];
@@ -210,7 +234,7 @@ __global__ __launch_bounds__(256) void k_likelihood_exact(PftParams prm, PftDev 
               }
             }
           }
-          const float reach = (float)rr * g * 0.9999f;  // everything closer than this has been seen
+          const float reach = (float)rr * gg;  // everything closer than this has been seen
           if (best < reach * reach || reach * reach > gate_f) break;
         }
       }
