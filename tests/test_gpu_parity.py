@@ -522,3 +522,55 @@ def test_exact_nearest_edge_cases(gpu, orc, data):
     np.testing.assert_array_equal(G["nn_idx"], O["nn_idx"])
     np.testing.assert_array_equal(G["nn_d2"], O["nn_d2"])
     assert ulp_diff(G["raw"], O["raw"]).max() <= 1
+
+
+@pytest.mark.parametrize("kind", ["lattice", "duplicates", "line", "growth_all_directions", "far_from_origin"])
+def test_eval_weights_adversarial_clouds(gpu, orc, data, kind, monkeypatch):
+    """input clouds built to sit on the octree's decision boundaries: points exactly on cell faces (coordinates that
+    are multiples of the resolution), many coincident points, a degenerate line, a box that has to grow in every
+    direction, and a scene 60 m from the origin (large float ulps); both builders"""
+    rng = np.random.default_rng(hash(kind) % 1000)
+    gt = np.array(data["gt"][:3], np.float32)
+    n = 6000
+    c = np.zeros(n, scene.POINT_DTYPE)
+    c["w"] = 1.0
+    c["rgba"] = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    if kind == "lattice":
+        xyz = np.round(rng.uniform(-0.3, 0.3, (n, 3)) / 0.01) * 0.01 + np.round(gt / 0.01) * 0.01
+    elif kind == "duplicates":
+        base = rng.uniform(-0.25, 0.25, (40, 3)) + gt
+        xyz = base[rng.integers(0, 40, n)]
+    elif kind == "line":
+        s = rng.uniform(-0.4, 0.4, n)
+        xyz = gt + np.stack([s, 0.3 * s, -0.2 * s], 1)
+    elif kind == "growth_all_directions":
+        r = np.linspace(0.001, 0.45, n)  # an outward spiral: every few points leave the box on another side
+        a = np.linspace(0, 60 * np.pi, n)
+        xyz = gt + np.stack([r * np.cos(a), r * np.sin(a), r * np.sin(2.3 * a)], 1)
+    else:
+        xyz = rng.uniform(-0.3, 0.3, (n, 3)) + gt
+    off = np.array([60.0, -35.0, 20.0], np.float32) if kind == "far_from_origin" else np.zeros(3, np.float32)
+    xyz = xyz.astype(np.float32) + off
+    c["x"], c["y"], c["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    P = 48
+    p = particles_around(tuple(np.array(data["gt"][:3]) + off) + tuple(data["gt"][3:]), P, 9, sig_t=0.03, sig_r=0.2)
+    trans = scene.initial_trans().copy()
+    trans[:3, 3] += off
+    for builder in ("single", "sorted"):
+        monkeypatch.setenv("PFT_FORCE_BUILDER", builder)
+        g = gpu.make_reference_tracker(particle_num=P, seed=1)
+        o = orc.Tracker(orc.default_config(particle_num=P, seed=1, threads=0, emulate_pcl_alloc=0))
+        for ref, tr, inp in ((g.setReferenceCloud, g.setTrans, g.setInputCloud), (o.set_reference, o.set_trans, o.set_input)):
+            ref(data["model"][:600])
+            tr(trans)
+            inp(c)
+        G = g.evalWeights(p, want_nn=True)
+        O = o.eval_weights(p, want_nn=True, mats=g.debugPoseToMatrix(p))
+        np.testing.assert_array_equal(G["crop_idx"], O["crop_idx"])
+        assert len(G["crop_idx"]) > 0 and G["octree_depth"] == O["octree_depth"]
+        np.testing.assert_array_equal(G["octree_min"], O["octree_min"])
+        ot = orc.Octree(np.ascontiguousarray(c)[O["crop_idx"]])
+        np.testing.assert_array_equal(G["point_keys"], ot.point_keys())
+        np.testing.assert_array_equal(G["nn_idx"], O["nn_idx"])
+        np.testing.assert_array_equal(G["nn_d2"], O["nn_d2"])
+        assert ulp_diff(G["raw"], O["raw"]).max() <= 1
