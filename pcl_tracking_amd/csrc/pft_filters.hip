@@ -329,7 +329,7 @@ __device__ __forceinline__ void store_point(pft_point_xyzrgba* o, float x, float
 //   k_fa_scatter   stable counting sort by entry: {x, y, z, rgba} and the input index in entry order
 //   k_fa_heads     run heads; the first point of every later run of an entry is a flush trigger (bit set)
 //   k_fa_ranks     one workgroup: trigger ranks per 32-point word, ranks of the non-empty entries, counts
-//   k_fa_emit      one thread per run: centroid in arrival order, written to its flush slot
+//   k_fa_emit_tile one thread per run, points staged in LDS: centroid in arrival order, written to its flush slot
 __device__ __forceinline__ uint32_t cell_entry(const FParams& p, float x, float y, float z, int& ix, int& iy, int& iz) {
   ix = floor_to_int(x * p.inv[0]);
   iy = floor_to_int(y * p.inv[1]);
@@ -430,6 +430,93 @@ __global__ __launch_bounds__(64) void k_fa_scatter(FParams p, FDev d, uint32_t n
   }
 }
 
+// The same stable counting sort with four waves per tile (table sizes up to 512): every wave ranks its own four
+// 64-point chunks with ballots, the per-chunk counts of every entry go to LDS, one pass over the 16 chunks turns them
+// into per-chunk offsets, and all 1024 moves are issued together.  No wave waits for another wave's running offsets.
+#define FS_MAXB 512u
+__global__ __launch_bounds__(F_THREADS) void k_fa_scatter4(FParams p, FDev d, uint32_t ntiles, int bits) {
+  constexpr uint32_t NCH = F_TILE / 64u;       // chunks per tile
+  constexpr uint32_t CPW = NCH / (F_THREADS / 64u);  // chunks per wave
+  __shared__ uint32_t cnt[FS_MAXB];
+  __shared__ uint32_t ccount[NCH * FS_MAXB / 4u];  // u8 [chunk][entry]: points of the entry in the chunk
+  __shared__ uint16_t cbase[NCH * FS_MAXB];        // u16 [chunk][entry]: points of the entry in earlier chunks of the tile
+  __shared__ uint32_t su[20];
+  const uint32_t t = blockIdx.x, tid = threadIdx.x, nb = p.hist_mask + 1u;
+  const int lane = lane_id(), w = wave_id();
+  const uint32_t* tot = d.hist + (size_t)nb * ntiles;
+  // keys of the wave's chunks (in flight while the bases are computed)
+  const uint32_t base = t * F_TILE;
+  uint32_t keys[CPW];
+#pragma unroll
+  for (uint32_t c = 0; c < CPW; c++) {
+    const uint32_t i = base + (w * CPW + c) * 64u + lane;
+    keys[c] = i < p.n ? (uint32_t)d.key16[i] : 0xFFFFu;
+  }
+  for (uint32_t k = tid; k < NCH * FS_MAXB / 4u; k += F_THREADS) ccount[k] = 0u;
+  {  // entry bases = exclusive scan of the entry totals (consecutive entries per thread) + this tile's offset
+    const uint32_t per = (nb + F_THREADS - 1u) / F_THREADS;
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < per; k++) {
+      const uint32_t b = tid * per + k;
+      if (b < nb) sum += tot[b];
+    }
+    uint32_t total;
+    uint32_t run = block_excl_scan<uint32_t>(sum, su, &total);  // (its barriers also publish the zeroed counts)
+    for (uint32_t k = 0; k < per; k++) {
+      const uint32_t b = tid * per + k;
+      if (b < nb) {
+        cnt[b] = run + d.hist[(size_t)b * ntiles + t];
+        run += tot[b];
+      }
+    }
+    if (t == 0 && tid == 0) d.hdr->n_pass = total;  // points that entered the grid
+  }
+  uint32_t rank[CPW];
+  uint8_t* cc8 = reinterpret_cast<uint8_t*>(ccount);
+#pragma unroll
+  for (uint32_t c = 0; c < CPW; c++) {
+    uint32_t key = keys[c];
+    const bool valid = key != 0xFFFFu;
+    if (!valid) key = 0;
+    unsigned long long peers = __ballot(valid);
+    if (!valid) peers = ~peers;
+    for (int b = 0; b < bits; b++) {
+      const unsigned long long m = __ballot((key >> b) & 1u);
+      peers &= ((key >> b) & 1u) ? m : ~m;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    rank[c] = __popcll(peers & lt);
+    if (valid && rank[c] == 0) cc8[(w * CPW + c) * FS_MAXB + key] = (uint8_t)__popcll(peers);
+    keys[c] = valid ? key : 0xFFFFu;
+  }
+  __syncthreads();
+  for (uint32_t b = tid; b < nb; b += F_THREADS) {  // per entry: offsets of the chunks inside the tile
+    uint32_t run = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < NCH; c++) {
+      cbase[c * FS_MAXB + b] = (uint16_t)run;
+      run += cc8[c * FS_MAXB + b];
+    }
+  }
+  __syncthreads();
+  uint32_t dst[CPW];
+#pragma unroll
+  for (uint32_t c = 0; c < CPW; c++) {
+    const uint32_t key = keys[c];
+    dst[c] = key != 0xFFFFu ? cnt[key] + cbase[(w * CPW + c) * FS_MAXB + key] + rank[c] : 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (uint32_t c = 0; c < CPW; c++) {
+    if (dst[c] != 0xFFFFFFFFu) {
+      const uint32_t i = base + (w * CPW + c) * 64u + lane;
+      const float4* q = reinterpret_cast<const float4*>(d.in + i);
+      const float4 a = q[0];
+      d.spt[dst[c]] = make_float4(a.x, a.y, a.z, q[1].x);
+      d.val[0][dst[c]] = i;
+    }
+  }
+}
+
 __global__ __launch_bounds__(F_THREADS) void k_fa_heads(FParams p, FDev d) {
   const uint32_t j = blockIdx.x * F_THREADS + threadIdx.x;
   const uint32_t nv = d.hdr->n_pass;
@@ -509,56 +596,6 @@ __global__ __launch_bounds__(1024) void k_fa_ranks(FParams p, FDev d, uint32_t n
   }
 }
 
-__global__ __launch_bounds__(F_THREADS) void k_fa_emit(FParams p, FDev d) {
-  const uint32_t j = blockIdx.x * F_THREADS + threadIdx.x;
-  if (j >= d.hdr->n_pass || !d.head[j]) return;
-  float sx = 0.0f, sy = 0.0f, sz = 0.0f, sr = 0.0f, sg = 0.0f, sb = 0.0f;
-  uint32_t e = j, hf;
-  float4 first;
-#define F_ACC(q)                                  \
-  do {                                            \
-    const uint32_t c_ = __float_as_uint((q).w);   \
-    sx += (q).x;                                  \
-    sy += (q).y;                                  \
-    sz += (q).z;                                  \
-    sr += (float)((c_ >> 16) & 255u);             \
-    sg += (float)((c_ >> 8) & 255u);              \
-    sb += (float)(c_ & 255u);                     \
-  } while (0)
-  for (;;) {  // four elements per round; loads past the run end are discarded (buffers are padded)
-    const float4 p0 = d.spt[e], p1 = d.spt[e + 1], p2 = d.spt[e + 2], p3 = d.spt[e + 3];
-    const uint32_t h1 = d.head[e + 1], h2 = d.head[e + 2], h3 = d.head[e + 3], h4 = d.head[e + 4];
-    if (e == j) first = p0;
-    F_ACC(p0);
-    if (h1) { e += 1; hf = h1; break; }
-    F_ACC(p1);
-    if (h2) { e += 2; hf = h2; break; }
-    F_ACC(p2);
-    if (h3) { e += 3; hf = h3; break; }
-    F_ACC(p3);
-    if (h4) { e += 4; hf = h4; break; }
-    e += 4;
-  }
-#undef F_ACC
-  const float cnt = (float)(e - j);
-  const int rgb = ((int)(sr / cnt)) << 16 | ((int)(sg / cnt)) << 8 | ((int)(sb / cnt));
-  uint32_t pos;
-  if (hf == 1) {  // flushed when the next voxel of this table entry arrived: rank of that trigger point
-    const uint32_t i = d.val[0][e];
-    pos = d.word_pref[i >> 5] + __popc(d.trig_bits[i >> 5] & ((1u << (i & 31u)) - 1u));
-  } else {  // still open at the end: flushed in table order
-    int ix, iy, iz;
-    pos = d.hdr->n_trig + d.bucket[cell_entry(p, first.x, first.y, first.z, ix, iy, iz)];
-  }
-  store_point(d.out + pos, sx / cnt, sy / cnt, sz / cnt, (uint32_t)rgb);
-}
-
-// The same centroids, one WAVE per 64 consecutive sorted points: the float sums of a run must be taken in
-// arrival order, so the adds stay serial, but the loads are one coalesced wave load and the serial part is
-// 64 steps of {6 lane broadcasts, 6 adds} with step l executed only on lanes >= l: lane L ends up holding
-// the running sum of its run up to and including its own point.  Lanes whose successor starts a new run
-// write an output point; the run still open at the end of the chunk is finished by the whole wave walking
-// on into the following chunks.  Replaces the thread-per-run loop above (3.5x faster at 518 400 points).
 struct RunOut {
   float sx, sy, sz, sr, sg, sb;
 };
@@ -578,77 +615,118 @@ __device__ __forceinline__ void emit_run(const FParams& p, const FDev& d, const 
   store_point(d.out + pos, s.sx / cnt, s.sy / cnt, s.sz / cnt, (uint32_t)rgb);
 }
 
-__global__ __launch_bounds__(F_THREADS) void k_fa_emit_wave(FParams p, FDev d) {
-  const uint32_t nv = d.hdr->n_pass;
-  const int lane = lane_id();
-  uint32_t c0 = (blockIdx.x * (F_THREADS / 64) + wave_id()) * 64u;
-  if (c0 >= nv) return;
-  const uint32_t j = c0 + lane;
-  float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  uint32_t h = 2;  // positions past the last point count as heads (the sentinel)
-  if (j < nv) {
-    q = d.spt[j];
-    h = d.head[j];
-  }
-  const uint32_t col = __float_as_uint(q.w);
-  const float fr = (float)((col >> 16) & 255u), fg = (float)((col >> 8) & 255u), fb = (float)(col & 255u);
-  const unsigned long long hm = __ballot(h != 0);
-  RunOut s = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+// Centroids, one workgroup per 1024 consecutive sorted points: the tile is loaded coalesced into LDS, the run heads
+// inside it are compacted into a list, and one THREAD per run walks its points in LDS (sequential float adds in
+// arrival order, as upstream; runs are 6 points long on average but reach ~200 on a depth frame).  The tile's last
+// run continues into the following tiles: the workgroup fetches 256 points at a time and one thread keeps adding.
+// (Measured at 518 400 points: 14 us; a thread per run reading HBM directly 90 us, a wave per 64 points with 64
+// lane-broadcast steps 26 us.)
+#define FE_TILE 1024u
+#define FE_THREADS (FE_TILE / 4u)
+__global__ __launch_bounds__(FE_THREADS) void k_fa_emit_tile(FParams p, FDev d) {
+  __shared__ float4 spts[FE_TILE];
+  __shared__ uint32_t shead[FE_TILE / 4];
+  __shared__ uint16_t srun[FE_TILE];
+  __shared__ uint32_t su[20];
+  const uint32_t base = blockIdx.x * FE_TILE, tid = threadIdx.x;
+  // The tile, its head flags and the first 256 points after it are requested before the point count is known (the
+  // buffers are padded to whole tiles; the tile index is below the input count): one memory round trip less.
+  float4 lq[FE_TILE / FE_THREADS];
 #pragma unroll
-  for (int l = 0; l < 64; l++) {
-    const float vx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.x), l));
-    const float vy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.y), l));
-    const float vz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q.z), l));
-    const float vr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fr), l));
-    const float vg = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fg), l));
-    const float vb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fb), l));
-    if (lane >= l) {
-      if ((hm >> l) & 1ull) {  // wave-uniform: point l starts a run
-        s.sx = 0.0f; s.sy = 0.0f; s.sz = 0.0f; s.sr = 0.0f; s.sg = 0.0f; s.sb = 0.0f;
-      }
-      s.sx += vx; s.sy += vy; s.sz += vz; s.sr += vr; s.sg += vg; s.sb += vb;
-    }
+  for (uint32_t k = 0; k < FE_TILE / FE_THREADS; k++) lq[k] = d.spt[base + k * FE_THREADS + tid];
+  uint32_t hw = *reinterpret_cast<const uint32_t*>(d.head + base + tid * 4u);  // four consecutive points
+  const uint32_t jh = base + FE_TILE + tid;
+  uint32_t h = jh <= p.n ? (uint32_t)d.head[jh] : 2u;
+  float4 cq = jh < p.n ? d.spt[jh] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  const uint32_t nv = d.hdr->n_pass;
+  if (base >= nv) return;
+  const uint32_t cnt_tile = min(FE_TILE, nv - base);
+#pragma unroll
+  for (uint32_t k = 0; k < FE_TILE / FE_THREADS; k++) spts[k * FE_THREADS + tid] = lq[k];
+  // positions past the last point never start a run (their flags are stale)
+#pragma unroll
+  for (uint32_t b = 0; b < 4; b++)
+    if (tid * 4u + b >= cnt_tile) hw &= ~(0xffu << (8u * b));
+  if (jh > nv || cnt_tile < FE_TILE) h = 2u;  // head[nv] is the sentinel; a short tile ends at it
+  shead[tid] = hw;
+  const uint32_t f0 = (hw & 0xffu) ? 1u : 0u, f1 = (hw & 0xff00u) ? 1u : 0u, f2 = (hw & 0xff0000u) ? 1u : 0u,
+                 f3 = (hw >> 24) ? 1u : 0u;
+  uint32_t R;
+  uint32_t o = block_excl_scan<uint32_t>(f0 + f1 + f2 + f3, su, &R);
+  if (f0) srun[o++] = (uint16_t)(tid * 4u);
+  if (f1) srun[o++] = (uint16_t)(tid * 4u + 1u);
+  if (f2) srun[o++] = (uint16_t)(tid * 4u + 2u);
+  if (f3) srun[o++] = (uint16_t)(tid * 4u + 3u);
+  __syncthreads();
+  const uint8_t* hb = reinterpret_cast<const uint8_t*>(shead);
+#define FE_ACC(q)                                 \
+  do {                                            \
+    const uint32_t c_ = __float_as_uint((q).w);   \
+    s.sx += (q).x;                                \
+    s.sy += (q).y;                                \
+    s.sz += (q).z;                                \
+    s.sr += (float)((c_ >> 16) & 255u);           \
+    s.sg += (float)((c_ >> 8) & 255u);            \
+    s.sb += (float)(c_ & 255u);                   \
+  } while (0)
+// adds stay in arrival order; four LDS reads are in flight per round
+#define FE_WALK(arr, from, to)                                                     \
+  do {                                                                             \
+    uint32_t l_ = (from);                                                          \
+    for (; l_ + 4u <= (to); l_ += 4u) {                                            \
+      const float4 q0 = arr[l_], q1 = arr[l_ + 1u], q2 = arr[l_ + 2u], q3 = arr[l_ + 3u]; \
+      FE_ACC(q0);                                                                  \
+      FE_ACC(q1);                                                                  \
+      FE_ACC(q2);                                                                  \
+      FE_ACC(q3);                                                                  \
+    }                                                                              \
+    for (; l_ < (to); l_++) {                                                      \
+      const float4 q0 = arr[l_];                                                   \
+      FE_ACC(q0);                                                                  \
+    }                                                                              \
+  } while (0)
+  for (uint32_t r = tid; r + 1u < R; r += FE_THREADS) {  // the runs that end inside the tile
+    const uint32_t s0 = srun[r], e0 = srun[r + 1u];
+    RunOut s = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const float4 first = spts[s0];
+    FE_WALK(spts, s0, e0);
+    emit_run(p, d, s, e0 - s0, first.x, first.y, first.z, hb[e0], base + e0);
   }
-  // my run's head inside this chunk (none: the run began in an earlier chunk and is finished by that wave)
-  const unsigned long long mine = hm & ((2ull << lane) - 1ull);
-  const bool started = mine != 0ull;
-  const uint32_t count = started ? (uint32_t)lane - (uint32_t)(63 - __clzll((long long)mine)) + 1u : 0u;
-  const uint32_t hnext = __shfl_down(h, 1);
-  if (lane < 63 && j < nv && started && hnext != 0) emit_run(p, d, s, count, q.x, q.y, q.z, hnext, j + 1);
-  // the run still open at lane 63
-  // (it exists if lane 63 is a real point; it is ours if its head lies in this chunk, i.e. the chunk has a head)
-  if (c0 + 63u >= nv || hm == 0ull) return;
-  RunOut u;
-  u.sx = __shfl(s.sx, 63); u.sy = __shfl(s.sy, 63); u.sz = __shfl(s.sz, 63);
-  u.sr = __shfl(s.sr, 63); u.sg = __shfl(s.sg, 63); u.sb = __shfl(s.sb, 63);
-  uint32_t ucount = __shfl(count, 63);
-  const float lx = __shfl(q.x, 63), ly = __shfl(q.y, 63), lz = __shfl(q.z, 63);
-  for (;;) {
-    c0 += 64u;
-    const uint32_t jj = c0 + lane;
-    float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    uint32_t g = 2;
-    if (jj < nv) {
-      r = d.spt[jj];
-      g = d.head[jj];
+  if (R == 0) return;  // (workgroup-uniform) the whole tile belongs to a run of an earlier tile
+  // The tile's last run may continue in the following tiles: the workgroup fetches 256 points at a time into LDS and
+  // finds the next head; one thread keeps adding in arrival order.
+  __shared__ float4 cpts[FE_THREADS];
+  __shared__ uint32_t sfirst[2], shf;
+  const uint32_t owner = FE_THREADS - 1u;
+  RunOut s = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  const uint32_t s0 = srun[R - 1u];
+  const float4 first = spts[s0];
+  if (tid == owner) FE_WALK(spts, s0, cnt_tile);
+  if (tid == 0) sfirst[0] = sfirst[1] = FE_THREADS;
+  __syncthreads();
+  uint32_t npos = base + cnt_tile;
+  for (uint32_t it = 0;; it++) {
+    if (it > 0) {
+      const uint32_t jj = npos + tid;
+      h = jj <= nv ? (uint32_t)d.head[jj] : 2u;
+      if (jj < nv) cq = d.spt[jj];
     }
-    const uint32_t rc = __float_as_uint(r.w);
-    const float rr = (float)((rc >> 16) & 255u), rg = (float)((rc >> 8) & 255u), rb = (float)(rc & 255u);
-    const unsigned long long gm = __ballot(g != 0);
-    const int f = gm ? __builtin_ctzll(gm) : 64;
-#define F_BCAST(v, l) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (v)), (l)))
-    for (int l = 0; l < f; l++) {  // wave-uniform trip count
-      u.sx += F_BCAST(r.x, l); u.sy += F_BCAST(r.y, l); u.sz += F_BCAST(r.z, l);
-      u.sr += F_BCAST(rr, l); u.sg += F_BCAST(rg, l); u.sb += F_BCAST(rb, l);
+    cpts[tid] = cq;
+    if (h) atomicMin(&sfirst[it & 1u], tid);
+    __syncthreads();
+    const uint32_t f = sfirst[it & 1u];
+    if (tid == f) shf = h;
+    if (tid == owner) {
+      sfirst[(it + 1u) & 1u] = FE_THREADS;
+      FE_WALK(cpts, 0u, f);
     }
-#undef F_BCAST
-    ucount += (uint32_t)f;
-    if (f < 64) {
-      const uint32_t gf = (uint32_t)__builtin_amdgcn_readlane((int)g, f);
-      if (lane == 0) emit_run(p, d, u, ucount, lx, ly, lz, gf, c0 + (uint32_t)f);
-      return;
-    }
+    __syncthreads();
+    npos += f;
+    if (f < FE_THREADS) break;
   }
+#undef FE_WALK
+#undef FE_ACC
+  if (tid == owner) emit_run(p, d, s, npos - (base + s0), first.x, first.y, first.z, shf, npos);
 }
 
 // VoxelGrid: one CentroidPoint per voxel, output in voxel-index order
@@ -895,14 +973,14 @@ static int run_pipeline(pft_filter* f, const pft_point_xyzrgba* d_in, size_t n) 
     while ((1u << bits) < nb) bits++;
     hipLaunchKernelGGL(k_fa_classify, dim3(ntiles), dim3(F_THREADS), 0, s, p, d, ntiles);
     hipLaunchKernelGGL(k_f_rs_scan, dim3(nb), dim3(F_THREADS), 0, s, d.hist, ntiles, nb);
-    hipLaunchKernelGGL(k_fa_scatter, dim3(ntiles), dim3(64), 0, s, p, d, ntiles, bits);
+    static const bool one_wave_scatter = getenv("PFT_FILTER_SCATTER1") != nullptr;  // A/B timing only
+    if (nb <= FS_MAXB && !one_wave_scatter)
+      hipLaunchKernelGGL(k_fa_scatter4, dim3(ntiles), dim3(F_THREADS), 0, s, p, d, ntiles, bits);
+    else
+      hipLaunchKernelGGL(k_fa_scatter, dim3(ntiles), dim3(64), 0, s, p, d, ntiles, bits);
     hipLaunchKernelGGL(k_fa_heads, dim3((uint32_t)((n + 1 + F_THREADS - 1) / F_THREADS)), dim3(F_THREADS), 0, s, p, d);
     hipLaunchKernelGGL(k_fa_ranks, dim3(1), dim3(1024), 0, s, p, d, ntiles);
-    static const bool thread_emit = getenv("PFT_FILTER_THREAD_EMIT") != nullptr;  // A/B timing only
-    if (thread_emit)
-      hipLaunchKernelGGL(k_fa_emit, dim3(nblk), dim3(F_THREADS), 0, s, p, d);
-    else
-      hipLaunchKernelGGL(k_fa_emit_wave, dim3(nblk), dim3(F_THREADS), 0, s, p, d);
+    hipLaunchKernelGGL(k_fa_emit_tile, dim3((uint32_t)((n + FE_TILE - 1) / FE_TILE)), dim3(FE_THREADS), 0, s, p, d);
     f->tile_pass_scanned = false;
   } else {
     hipLaunchKernelGGL(k_f_classify, dim3(ntiles), dim3(F_THREADS), 0, s, p, d);

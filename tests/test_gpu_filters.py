@@ -88,6 +88,29 @@ def test_approx_voxel_grid_ragged_sizes(F, orc, n):
     same_cloud(g.filter(), orc.approx_voxel_grid(c, (0.05, 0.02, 0.1), 512))
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_approx_voxel_grid_long_runs_across_tiles(F, orc, seed):
+    """runs of very different lengths (1 ... 2500 consecutive points of one voxel) that start and end at arbitrary
+    offsets of the 1024-point device tiles, over few voxels so that table entries collide and flush each other"""
+    rng = np.random.default_rng(seed)
+    lens = rng.choice([1, 2, 3, 7, 60, 255, 256, 257, 700, 1024, 2500], 120)
+    vox = rng.integers(0, 40, (len(lens), 3))  # 40^3 voxels over 512 table entries: collisions are common
+    cell = np.repeat(vox, lens, axis=0)
+    n = len(cell)
+    c = np.zeros(n, scene.POINT_DTYPE)
+    jit = rng.uniform(0.05, 0.95, (n, 3))
+    for a, k in enumerate(("x", "y", "z")):
+        c[k] = ((cell[:, a] + jit[:, a]) * 0.01).astype(np.float32)
+    c["w"] = 1.0
+    c["rgba"] = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    for hist in (512, 64, 1024):
+        g = F.ApproximateVoxelGrid()
+        g.setLeafSize(0.01)
+        g.setHistorySize(hist)
+        g.setInputCloud(c)
+        same_cloud(g.filter(), orc.approx_voxel_grid(c, 0.01, hist))
+
+
 def test_approx_voxel_grid_edge_cases(F, orc):
     g = F.ApproximateVoxelGrid()
     g.setLeafSize(0.01)
