@@ -729,45 +729,117 @@ __global__ __launch_bounds__(FE_THREADS) void k_fa_emit_tile(FParams p, FDev d) 
   if (tid == owner) emit_run(p, d, s, npos - (base + s0), first.x, first.y, first.z, shf, npos);
 }
 
-// VoxelGrid: one CentroidPoint per voxel, output in voxel-index order
-__global__ __launch_bounds__(F_THREADS) void k_f_emit_exact(FParams p, FDev d, const uint32_t* __restrict__ skey,
-                                                            const uint32_t* __restrict__ sval) {
+// VoxelGrid: one CentroidPoint per voxel, output in voxel-index order.  Same shape as k_fa_emit_tile: the 1024 sorted
+// entries of a tile are gathered (through the sorted input indices) into LDS by all threads at once, one thread per
+// run adds in sorted order (= input order inside a voxel), the tile's last run continues 256 entries at a time.
+// Entries at or after n_pass are the dropped points (key F_INVALID sorts last).
+struct RunOutA {
+  float sx, sy, sz, sr, sg, sb, sa;
+};
+
+__global__ __launch_bounds__(FE_THREADS) void k_f_emit_exact(FParams p, FDev d, const uint32_t* __restrict__ sval) {
+  __shared__ float4 spts[FE_TILE];
+  __shared__ uint16_t srun[FE_TILE];
   __shared__ uint32_t su[20];
-  const uint32_t t = blockIdx.x, tid = threadIdx.x;
-  const uint32_t j0 = t * F_TILE + tid * 4;
+  __shared__ float4 cpts[FE_THREADS];
+  __shared__ uint32_t sfirst[2];
+  const uint32_t t = blockIdx.x, base = t * FE_TILE, tid = threadIdx.x;
+  const uint32_t nv = d.hdr->n_pass;
+  if (base >= nv || d.hdr->leaf_too_small) return;
+  const uint32_t cnt_tile = min(FE_TILE, nv - base);
+#pragma unroll
+  for (uint32_t k = 0; k < FE_TILE / FE_THREADS; k++) {
+    const uint32_t l = k * FE_THREADS + tid;
+    if (l < cnt_tile) {
+      const float4* q = reinterpret_cast<const float4*>(d.in + sval[base + l]);
+      const float4 a = q[0];
+      spts[l] = make_float4(a.x, a.y, a.z, q[1].x);
+    }
+  }
   uint32_t f[4], cnt = 0;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    f[k] = (j0 + k < p.n) ? d.head[j0 + k] : 0u;
-    cnt += f[k];
+  for (uint32_t b = 0; b < 4; b++) {
+    const uint32_t l = tid * 4u + b;
+    f[b] = l < cnt_tile ? (uint32_t)d.head[base + l] : 0u;
+    cnt += f[b];
   }
-  uint32_t tot;
-  uint32_t pos = d.tile_head[t] + block_excl_scan<uint32_t>(cnt, su, &tot);
-  if (d.hdr->leaf_too_small) return;
-  for (int k = 0; k < 4; k++) {
-    if (!f[k]) continue;
-    const uint32_t j = j0 + k, b = skey[j];
-    float sx = 0.0f, sy = 0.0f, sz = 0.0f, sr = 0.0f, sg = 0.0f, sb = 0.0f, sa = 0.0f;
-    uint32_t e = j, count = 0;
-    do {
-      const float4* q = reinterpret_cast<const float4*>(d.in + sval[e]);
+  uint32_t R;
+  uint32_t o = block_excl_scan<uint32_t>(cnt, su, &R);
+#pragma unroll
+  for (uint32_t b = 0; b < 4; b++)
+    if (f[b]) srun[o++] = (uint16_t)(tid * 4u + b);
+  __syncthreads();
+  const uint32_t out0 = d.tile_head[t];
+#define FX_ACC(q)                               \
+  do {                                          \
+    const uint32_t c_ = __float_as_uint((q).w); \
+    s.sx += (q).x;                              \
+    s.sy += (q).y;                              \
+    s.sz += (q).z;                              \
+    s.sr += (float)((c_ >> 16) & 255u);         \
+    s.sg += (float)((c_ >> 8) & 255u);          \
+    s.sb += (float)(c_ & 255u);                 \
+    s.sa += (float)(c_ >> 24);                  \
+  } while (0)
+#define FX_WALK(arr, from, to)                                                            \
+  do {                                                                                    \
+    uint32_t l_ = (from);                                                                 \
+    for (; l_ + 4u <= (to); l_ += 4u) {                                                   \
+      const float4 q0 = arr[l_], q1 = arr[l_ + 1u], q2 = arr[l_ + 2u], q3 = arr[l_ + 3u]; \
+      FX_ACC(q0);                                                                         \
+      FX_ACC(q1);                                                                         \
+      FX_ACC(q2);                                                                         \
+      FX_ACC(q3);                                                                         \
+    }                                                                                     \
+    for (; l_ < (to); l_++) {                                                             \
+      const float4 q0 = arr[l_];                                                          \
+      FX_ACC(q0);                                                                         \
+    }                                                                                     \
+  } while (0)
+#define FX_EMIT(slot, count)                                                                                     \
+  do {                                                                                                           \
+    const float c = (float)(count);                                                                              \
+    const uint32_t rgba =                                                                                        \
+        (uint32_t)(s.sa / c) << 24 | (uint32_t)(s.sr / c) << 16 | (uint32_t)(s.sg / c) << 8 | (uint32_t)(s.sb / c); \
+    store_point(d.out + (slot), s.sx / c, s.sy / c, s.sz / c, rgba);                                             \
+  } while (0)
+  for (uint32_t r = tid; r + 1u < R; r += FE_THREADS) {  // the runs that end inside the tile
+    const uint32_t s0 = srun[r], e0 = srun[r + 1u];
+    RunOutA s = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    FX_WALK(spts, s0, e0);
+    FX_EMIT(out0 + r, e0 - s0);
+  }
+  if (R == 0) return;  // (workgroup-uniform) the whole tile belongs to a run of an earlier tile
+  const uint32_t owner = FE_THREADS - 1u;
+  RunOutA s = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  const uint32_t s0 = srun[R - 1u];
+  if (tid == owner) FX_WALK(spts, s0, cnt_tile);
+  if (tid == 0) sfirst[0] = sfirst[1] = FE_THREADS;
+  __syncthreads();
+  uint32_t npos = base + cnt_tile;
+  for (uint32_t it = 0;; it++) {
+    const uint32_t jj = npos + tid;
+    const uint32_t h = jj < nv ? (uint32_t)d.head[jj] : 1u;  // the end of the kept points ends the last run
+    if (jj < nv) {
+      const float4* q = reinterpret_cast<const float4*>(d.in + sval[jj]);
       const float4 a = q[0];
-      const uint32_t rgba = __float_as_uint(q[1].x);
-      sx += a.x;
-      sy += a.y;
-      sz += a.z;
-      sr += (float)((rgba >> 16) & 255u);
-      sg += (float)((rgba >> 8) & 255u);
-      sb += (float)(rgba & 255u);
-      sa += (float)(rgba >> 24);
-      count++;
-      e++;
-    } while (e < p.n && skey[e] == b);
-    const float c = (float)count;
-    const uint32_t rgba = (uint32_t)(sa / c) << 24 | (uint32_t)(sr / c) << 16 | (uint32_t)(sg / c) << 8 | (uint32_t)(sb / c);
-    store_point(d.out + pos, sx / c, sy / c, sz / c, rgba);
-    pos++;
+      cpts[tid] = make_float4(a.x, a.y, a.z, q[1].x);
+    }
+    if (h) atomicMin(&sfirst[it & 1u], tid);
+    __syncthreads();
+    const uint32_t fpos = sfirst[it & 1u];
+    if (tid == owner) {
+      sfirst[(it + 1u) & 1u] = FE_THREADS;
+      FX_WALK(cpts, 0u, fpos);
+    }
+    __syncthreads();
+    npos += fpos;
+    if (fpos < FE_THREADS) break;
   }
+  if (tid == owner) FX_EMIT(out0 + R - 1u, npos - (base + s0));
+#undef FX_EMIT
+#undef FX_WALK
+#undef FX_ACC
 }
 
 // PassThrough alone: the kept points, stable (sorted position j < n_pass holds input index sval[j])
@@ -1004,7 +1076,7 @@ static int run_pipeline(pft_filter* f, const pft_point_xyzrgba* d_in, size_t n) 
     if (p.mode == PFT_VOXEL_EXACT) {
       hipLaunchKernelGGL(k_f_heads_exact, dim3(ntiles), dim3(F_THREADS), 0, s, p, d, skey);
       hipLaunchKernelGGL(k_f_scan_small, dim3(1), dim3(1024), 0, s, p, d, ntiles);
-      hipLaunchKernelGGL(k_f_emit_exact, dim3(ntiles), dim3(F_THREADS), 0, s, p, d, skey, sval);
+      hipLaunchKernelGGL(k_f_emit_exact, dim3(ntiles), dim3(FE_THREADS), 0, s, p, d, sval);
     } else {
       hipLaunchKernelGGL(k_f_scan_small, dim3(1), dim3(1024), 0, s, p, d, ntiles);
       hipLaunchKernelGGL(k_f_gather, dim3(nblk), dim3(F_THREADS), 0, s, p, d, sval);
