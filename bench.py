@@ -298,6 +298,19 @@ def main():
                 "launches": int(lik_n),
             },
         }
+        if P_local == P_PER_GPU and M == M_MODEL and N == N_CLOUD and not ARGS.organized:
+            # interpretation aid (SURVEY 8d "secondary (VALU) roof"): the kernel's working set is LDS/L2-resident and it
+            # is VALU-issue bound.  Instruction count per launch from the committed PMC pass of this very workload
+            # (profiles/r01_pmc_sq_counters.txt: SQ_INSTS_VALU of k_likelihood<false>); the duration is the live one.
+            valu_insts = 1.554e8
+            # nominal issue rate: one wave64 VALU instruction per 4 cycles per SIMD, 1024 SIMDs at 2.4 GHz.  Measured
+            # on this part (tools/micro/valu_rate_test.hip): compares, selects, shifts, bit-field and 3-operand
+            # instructions take 4.1-4.4 cycles, plain add/sub/mul/and/or 2.5-2.7 -- about a third of this kernel's mix.
+            valu_peak = 256 * 4 * 2.4e9 / 4.0
+            out["roofline"]["valu_issue"] = {
+                "wave_insts_per_launch": valu_insts, "wave_insts_per_s": valu_insts / lik_avg_s,
+                "nominal_peak_wave_insts_per_s": valu_peak, "frac_of_nominal": valu_insts / lik_avg_s / valu_peak,
+                "source": "profiles/r01_pmc_sq_counters.txt (SQ_INSTS_VALU of this workload); duration measured live"}
         if world == 1 and not ARGS.no_cpu_baseline:
             cores = os.cpu_count() or 1
             tmin, tmed, stages = cpu_baseline(model, cloud, trans, P_total, cores)
