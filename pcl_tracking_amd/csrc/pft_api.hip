@@ -67,6 +67,8 @@ struct pft_tracker {
   double* d_alias_pref = nullptr;
   double* d_pop_part = nullptr;
   uint32_t *d_eg_start = nullptr, *d_eg_cnt = nullptr, *d_eg_tile = nullptr;
+  uint32_t *d_ec_slot = nullptr, *d_ec_cells = nullptr, *d_ec_count = nullptr, *d_ec_base = nullptr;
+  float4* d_ec_list = nullptr;
   uint32_t* d_kld_table = nullptr;
   int32_t* d_kld_bins = nullptr;
   uint32_t dbg_builds = 0;
@@ -319,6 +321,11 @@ static void sync_dev(pft_tracker* t) {
   d.eg_cnt = t->d_eg_cnt;
   d.eg_tile = t->d_eg_tile;
   d.eg_cap = t->d_eg_start ? PFT_EG_CAP : 0u;
+  d.ec_slot = t->d_ec_slot;
+  d.ec_cells = t->d_ec_cells;
+  d.ec_count = t->d_ec_count;
+  d.ec_base = t->d_ec_base;
+  d.ec_list = t->d_ec_list;
   d.kld_table = t->d_kld_table;
   d.kld_bins = t->d_kld_bins;
   d.alias_pos = t->d_alias_pos;
@@ -450,6 +457,11 @@ extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
     A(dalloc(&t->d_eg_start, (size_t)PFT_EG_CAP + 1));
     A(dalloc(&t->d_eg_cnt, (size_t)PFT_EG_CAP));
     A(dalloc(&t->d_eg_tile, (size_t)PFT_EG_CAP / 2048 + 2));
+    A(dalloc(&t->d_ec_slot, (size_t)PFT_EG_CAP));
+    A(dalloc(&t->d_ec_cells, (size_t)PFT_EC_SLOTS));
+    A(dalloc(&t->d_ec_count, (size_t)PFT_EC_SLOTS));
+    A(dalloc(&t->d_ec_base, (size_t)PFT_EC_SLOTS));
+    A(dalloc(&t->d_ec_list, (size_t)PFT_EC_POOL));
   }
   if (p.kld) {
     A(dalloc(&t->d_kld_table, (size_t)6 * p.kld_max + 128));
@@ -501,7 +513,7 @@ extern "C" void pft_destroy(pft_tracker* t) {
   dfree(t->d_pt_key64); dfree(t->sort.keys[0]); dfree(t->sort.keys[1]); dfree(t->sort.vals[0]); dfree(t->sort.vals[1]);
   dfree(t->sort.hist); dfree(t->sort.tile_cnt); dfree(t->sort.tile_box); if (t->h_stat) hipHostFree(t->h_stat);
   dfree(t->d_partial); dfree(t->d_alias_list); dfree(t->d_alias_pos);
-  dfree(t->d_alias_pref); dfree(t->d_pop_part); dfree(t->d_kld_table); dfree(t->d_kld_bins); dfree(t->d_eg_start); dfree(t->d_eg_cnt); dfree(t->d_eg_tile); dfree(t->d_hdr); dfree(t->d_nn_idx); dfree(t->d_nn_d2); dfree(t->d_dbg_part);
+  dfree(t->d_alias_pref); dfree(t->d_pop_part); dfree(t->d_kld_table); dfree(t->d_kld_bins); dfree(t->d_eg_start); dfree(t->d_eg_cnt); dfree(t->d_eg_tile); dfree(t->d_ec_slot); dfree(t->d_ec_cells); dfree(t->d_ec_count); dfree(t->d_ec_base); dfree(t->d_ec_list); dfree(t->d_hdr); dfree(t->d_nn_idx); dfree(t->d_nn_d2); dfree(t->d_dbg_part);
   dfree(t->d_dbg_hdr); dfree(t->d_dbg_f);
   if (t->own_stream && t->stream) hipStreamDestroy(t->stream);
   delete t;

@@ -5,10 +5,14 @@
 // point coherences as the approximate variant.
 //
 // Only neighbours inside the gate contribute, so the search structure is a uniform grid over the crop box with a cell
-// of two octree leaves (2 cm): counting sort of the cropped points by cell (three small kernels per iteration), then
-// per query shells of growing radius (in cells) around the query's cell are scanned, row segment by row segment,
-// with rows farther than the best distance skipped, until the reach exceeds the best distance found (or the gate).  Nearest = smallest float distance, equal distances -> lowest index
-// (upstream leaves ties to std::sort).  No octree is built in this mode.
+// of two octree leaves (2 cm): counting sort of the cropped points by cell (small kernels, every iteration).  The
+// queries of an iteration fall into a few ten thousand of its cells; for each of those cells the points that can be
+// the nearest neighbour of ANY query inside it are collected once (k_ec_mark / k_ec_slots / k_ec_build: "candidate
+// lists"), and a query walks its cell's list -- about 90 candidates on the bench workload instead of the thousands a
+// per-query search of the 10 cm gate visits.  Nearest = smallest float pointSquaredDist, equal distances -> lowest
+// cloud index (upstream leaves ties to std::sort).  The per-query shell search (rings of grid rows of growing radius)
+// remains as the path for queries outside the grid and for cells that found the list pool full.  No octree is built
+// in this mode.
 #include "pft_device_utils.h"
 
 #define EG_TILE 2048u
@@ -46,11 +50,16 @@ __global__ void k_eg_setup(PftParams prm, PftDev d) {
     h->eg_min[a] = h->bbox[2 * a];
   }
   h->eg_ncells = n > 0 ? (uint32_t)(dim[0] * dim[1] * dim[2]) : 0u;
+  h->ec_nslots = 0u;
+  h->ec_pool_used = 0u;
 }
 
 __global__ __launch_bounds__(256) void k_eg_zero(PftDev d) {
   const uint32_t nc = d.hdr->eg_ncells;
-  for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < min(nc, (blockIdx.x + 1u) * 1024u); i += 256u) d.eg_cnt[i] = 0u;
+  for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < min(nc, (blockIdx.x + 1u) * 1024u); i += 256u) {
+    d.eg_cnt[i] = 0u;
+    d.ec_slot[i] = 0u;
+  }
 }
 
 __device__ __forceinline__ uint32_t eg_cell_of(const PftHeader* h, float x, float y, float z) {
@@ -142,9 +151,249 @@ void pftk_exact_grid(hipStream_t s, const PftParams& p, const PftDev& d) {
   hipLaunchKernelGGL(k_eg_scatter, dim3(nb ? nb : 1), dim3(256), 0, s, d);
 }
 
+// ---- candidate lists ----
+// The queries of one iteration (P x M of them) fall into a few ten thousand grid cells.  For a cell with centre m and
+// half diagonal r, let D = distance from m to the nearest cloud point.  A query q of that cell has its nearest
+// neighbour no farther than D + r, so every point that can be the nearest neighbour (or tie with it) of ANY query of
+// the cell lies within D + 2r of m -- and only neighbours inside the gate count, so within gate + r as well.  These
+// few dozen to few hundred points are collected ONCE per cell (one wave per cell, lanes over grid rows); a query then
+// only walks its cell's list.  The lists live in one pool (PFT_EC_POOL entries); cells that find it full and queries
+// outside the grid take the shell search below.
+#define EC_NOLIST 0xffffffffu
+
+// unclamped cell coordinates of a query; false if it lies outside the grid
+__device__ __forceinline__ bool eg_query_cell(const PftHeader* h, float qx, float qy, float qz, int& cx, int& cy, int& cz) {
+  cx = (int)floorf((qx - h->eg_min[0]) * h->eg_inv_g);
+  cy = (int)floorf((qy - h->eg_min[1]) * h->eg_inv_g);
+  cz = (int)floorf((qz - h->eg_min[2]) * h->eg_inv_g);
+  return cx >= 0 && cx < h->eg_dim[0] && cy >= 0 && cy < h->eg_dim[1] && cz >= 0 && cz < h->eg_dim[2];
+}
+
+// every query flags its cell
+__global__ __launch_bounds__(256) void k_ec_mark(PftParams prm, PftDev d, uint32_t n_particles) {
+  PftHeader* h = d.hdr;
+  if (h->n_crop == 0) return;
+  if (d.p_active) n_particles = *d.p_active;
+  const uint32_t M = prm.M, nblk = (M + 511u) / 512u;
+  const int lane = lane_id(), nw = blockDim.x >> 6;
+  const uint32_t gw = blockIdx.x * nw + wave_id(), tw = gridDim.x * nw;
+  const uint32_t n_items = n_particles * nblk;
+  for (uint32_t item_v = gw; item_v < n_items; item_v += tw) {
+    const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item_v);
+    const uint32_t pi = item / nblk, ch = item % nblk;
+    float T[12];
+    load_matrix(d.mats, pi, T);
+    const uint32_t jend = min(M, (ch + 1u) * 512u);
+    for (uint32_t j = ch * 512u + lane; j < jend; j += WAVE) {
+      const float4 r = d.ref_xyz[j];
+      float qx, qy, qz;
+      xform(T, r.x, r.y, r.z, qx, qy, qz);
+      int cx, cy, cz;
+      if (!eg_query_cell(h, qx, qy, qz, cx, cy, cz)) continue;
+      const uint32_t c = (uint32_t)((cz * h->eg_dim[1] + cy) * h->eg_dim[0] + cx);
+      if (d.ec_slot[c] == 0u) d.ec_slot[c] = 1u;  // idempotent: no atomic needed
+    }
+  }
+}
+
+// the flagged cells get list slots (order irrelevant)
+__global__ __launch_bounds__(256) void k_ec_slots(PftDev d) {
+  PftHeader* h = d.hdr;
+  const uint32_t nc = h->n_crop ? h->eg_ncells : 0u;
+  for (uint32_t c0 = blockIdx.x * 256u; c0 < nc; c0 += gridDim.x * 256u) {
+    const uint32_t c = c0 + threadIdx.x;
+    const bool hit = c < nc && d.ec_slot[c] == 1u;
+    const unsigned long long m = __ballot(hit);
+    if (!m) continue;
+    uint32_t base = 0;
+    if (lane_id() == __ffsll((long long)m) - 1) base = atomicAdd(&h->ec_nslots, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, __ffsll((long long)m) - 1);
+    if (hit) {
+      const uint32_t sl = base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+      if (sl < PFT_EC_SLOTS) {
+        d.ec_cells[sl] = c;
+        d.ec_slot[c] = sl + 2u;
+      } else {
+        d.ec_slot[c] = EC_NOLIST;
+      }
+    }
+  }
+}
+
+// one wave per list: D, then the points within min(D + 2r, gate + r) of the cell centre
+__global__ __launch_bounds__(256) void k_ec_build(PftParams prm, PftDev d) {
+  __shared__ uint32_t wcnt[4];
+  const PftHeader* h = d.hdr;
+  const uint32_t ns = min(h->ec_nslots, (uint32_t)PFT_EC_SLOTS);
+  const float g = h->eg_g, inv_g = h->eg_inv_g, hh = 0.5f * h->eg_g;
+  const int dx_ = h->eg_dim[0], dy_ = h->eg_dim[1], dz_ = h->eg_dim[2];
+  const float r = hh * 1.7320508f + 1.0e-4f;  // half diagonal of a cell + slack for the float cell assignment
+  const float gate = sqrtf((float)prm.maxd2);
+  const int lane = lane_id(), w = wave_id(), nw = blockDim.x >> 6;
+  const uint32_t gw = blockIdx.x * nw + w, tw = gridDim.x * nw;
+  const int Kmax = (int)ceilf((gate + r) * inv_g) + 1;
+  for (uint32_t s = gw; s < ns; s += tw) {  // wave-uniform
+    const uint32_t c = d.ec_cells[s];
+    const int cx = (int)(c % (uint32_t)dx_), cy = (int)((c / (uint32_t)dx_) % (uint32_t)dy_),
+              cz = (int)(c / (uint32_t)(dx_ * dy_));
+    const float mx = h->eg_min[0] + ((float)cx + 0.5f) * g, my = h->eg_min[1] + ((float)cy + 0.5f) * g,
+                mz = h->eg_min[2] + ((float)cz + 0.5f) * g;
+    // ---- D: shells of rows around the cell, lanes over rows ----
+    float best = INFINITY;
+    bool none = false;
+    for (int k = 0; k <= Kmax; k++) {
+      const int side = 2 * k + 1;
+      for (int t = lane; t < side * side; t += WAVE) {
+        const int oz = t / side - k, oy = t % side - k;
+        const int z = cz + oz, y = cy + oy;
+        if (z < 0 || z >= dz_ || y < 0 || y >= dy_) continue;
+        const uint32_t row = (uint32_t)((z * dy_ + y) * dx_);
+        const bool face = abs(oz) == k || abs(oy) == k;
+        for (int sg = 0; sg < (face ? 1 : 2); sg++) {
+          int x0, x1;
+          if (face) {
+            x0 = max(cx - k, 0);
+            x1 = min(cx + k, dx_ - 1);
+          } else {
+            x0 = x1 = sg == 0 ? cx - k : cx + k;
+            if (x0 < 0 || x0 >= dx_) continue;
+          }
+          const uint32_t s0 = d.eg_start[row + (uint32_t)x0], s1 = d.eg_start[row + (uint32_t)x1 + 1u];
+          for (uint32_t pos = s0; pos < s1; pos++) {
+            const float4 p = d.leaf_pts[pos];
+            const float ex = p.x - mx, ey = p.y - my, ez = p.z - mz;
+            best = fminf(best, ex * ex + (ey * ey + ez * ez));
+          }
+        }
+      }
+      const float wb = wave_min(best);
+      const float reach = (float)k * g + hh;  // every point not seen yet is at least this far from the centre
+      if (wb <= reach * reach * 0.999f) break;
+      if (reach - r > gate) {  // no query of this cell has a neighbour inside the gate
+        none = true;
+        break;
+      }
+    }
+    const float D = sqrtf(wave_min(best));
+    if (none || !(D - r <= gate)) {
+      if (lane == 0) d.ec_count[s] = 0u;
+      continue;
+    }
+    const float T = fminf(D + 2.0f * r, gate + r) + 1.0e-4f, T2 = T * T;
+    // ---- the list: rows within T of the centre, lanes over rows; counted first, then allotted in the pool, then written ----
+    const int KT = (int)ceilf((T + hh) * inv_g), side = 2 * KT + 1;
+    uint32_t total = 0, base = 0;
+    for (int pass = 0; pass < 2; pass++) {
+      uint32_t mine = 0;
+      for (int t = lane; t < side * side; t += WAVE) {
+        const int oz = t / side - KT, oy = t % side - KT;
+        const int z = cz + oz, y = cy + oy;
+        if (z < 0 || z >= dz_ || y < 0 || y >= dy_) continue;
+        const float lz = fmaxf((float)abs(oz) * g - hh, 0.0f) * 0.9999f, ly = fmaxf((float)abs(oy) * g - hh, 0.0f) * 0.9999f;
+        const float lyz = ly * ly + lz * lz;
+        if (lyz > T2) continue;
+        const int kx = (int)floorf((sqrtf(T2 - lyz) + hh) * inv_g) + 1;
+        const int x0 = max(cx - kx, 0), x1 = min(cx + kx, dx_ - 1);
+        const uint32_t row = (uint32_t)((z * dy_ + y) * dx_);
+        const uint32_t s0 = d.eg_start[row + (uint32_t)x0], s1 = d.eg_start[row + (uint32_t)x1 + 1u];
+        for (uint32_t pos = s0; pos < s1; pos++) {
+          const float4 p = d.leaf_pts[pos];
+          const float ex = p.x - mx, ey = p.y - my, ez = p.z - mz;
+          if (ex * ex + (ey * ey + ez * ez) <= T2) {
+            if (pass == 1) d.ec_list[base + atomicAdd(&wcnt[w], 1u)] = make_float4(p.x, p.y, p.z, __uint_as_float(pos));
+            mine++;
+          }
+        }
+      }
+      if (pass == 0) {
+        total = wave_sum(mine);
+        if (lane == 0) {
+          base = atomicAdd(&d.hdr->ec_pool_used, total);
+          wcnt[w] = 0u;
+        }
+        base = (uint32_t)__shfl((int)base, 0);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (base + total > PFT_EC_POOL || base + total < base) {  // (wave-uniform) the pool is full: no list for this cell
+          total = EC_NOLIST;
+          break;
+        }
+      }
+    }
+    if (lane == 0) {
+      d.ec_count[s] = total;
+      d.ec_base[s] = base;
+    }
+  }
+}
+
+struct EgHit {
+  float best;
+  uint32_t bi;
+  float4 bt;
+};
+
+__device__ __forceinline__ void eg_take(const PftDev& d, uint32_t pos, float qx, float qy, float qz, EgHit& b) {
+  const float4 p = d.leaf_pts[pos];
+  const float ex = p.x - qx, ey = p.y - qy, ez = p.z - qz;
+  const float dd = ex * ex + (ey * ey + ez * ez);  // pointSquaredDist
+  if (dd <= b.best) {
+    const uint32_t idx = d.leaf_order[pos];
+    if (dd < b.best || idx < b.bi) {  // equal distances: the lowest index
+      b.best = dd;
+      b.bi = idx;
+      b.bt = p;
+    }
+  }
+}
+
+// Shells of growing Chebyshev radius rr around the query's cell (cells not clamped: a query outside the box starts its
+// rings outside).  The cells of one (z, y) row are contiguous in the sorted order, so a row segment costs two loads of
+// cell starts however many cells it spans: rows on the shell's faces are scanned over their whole x range, inner rows
+// only at their two end cells.  A row whose cells are all farther than the best distance so far is skipped before
+// anything is loaded (a point in a row at offset o is at least (|o| - 1) cells away on that axis), and once shell rr is
+// done everything closer than rr * g has been seen.
+__device__ void eg_shell_search(const PftDev& d, int cqx, int cqy, int cqz, float g, int dx_, int dy_, int dz_, int R,
+                                float gate_f, float qx, float qy, float qz, EgHit& b) {
+  const float gg = g * 0.9999f;
+  for (int rr = 0; rr <= R; rr++) {
+    for (int oz = -rr; oz <= rr; oz++) {
+      const int cz = cqz + oz;
+      if (cz < 0 || cz >= dz_) continue;
+      const float lz = (float)max(abs(oz) - 1, 0) * gg;
+      for (int oy = -rr; oy <= rr; oy++) {
+        const int cy = cqy + oy;
+        if (cy < 0 || cy >= dy_) continue;
+        const float ly = (float)max(abs(oy) - 1, 0) * gg;
+        const float lyz = ly * ly + lz * lz;
+        const bool face = (abs(oz) == rr) || (abs(oy) == rr);
+        const float lx = face ? 0.0f : (float)max(rr - 1, 0) * gg;
+        if (lyz + lx * lx > fminf(b.best, gate_f)) continue;
+        const uint32_t row = (uint32_t)((cz * dy_ + cy) * dx_);
+        const int nseg = (face || rr == 0) ? 1 : 2;
+        for (int sgi = 0; sgi < nseg; sgi++) {
+          int x0, x1;
+          if (nseg == 1) {
+            x0 = max(cqx - rr, 0);
+            x1 = min(cqx + rr, dx_ - 1);
+          } else {
+            x0 = x1 = sgi == 0 ? cqx - rr : cqx + rr;
+            if (x0 < 0 || x0 >= dx_) continue;
+          }
+          if (x0 > x1) continue;
+          const uint32_t s0 = d.eg_start[row + (uint32_t)x0], s1 = d.eg_start[row + (uint32_t)x1 + 1u];
+          for (uint32_t pos = s0; pos < s1; pos++) eg_take(d, pos, qx, qy, qz, b);
+        }
+      }
+    }
+    const float reach = (float)rr * gg;  // everything closer than this has been seen
+    if (b.best < reach * reach || reach * reach > gate_f) break;
+  }
+}
+
 // ---- A7 with the exact nearest neighbour ----
 template <bool DEBUG_NN>
-__global__ __launch_bounds__(256) void k_likelihood_exact(PftParams prm, PftDev d, uint32_t n_particles) {
+__global__ __launch_bounds__(256) void k_likelihood_exact(PftParams prm, PftDev d, uint32_t n_particles, int use_lists) {
   __shared__ float lut_h[256], lut_s[256];
   const PftHeader* h = d.hdr;
   if (d.p_active) n_particles = *d.p_active;
@@ -155,7 +404,6 @@ __global__ __launch_bounds__(256) void k_likelihood_exact(PftParams prm, PftDev 
   __syncthreads();
   const uint32_t n_crop = h->n_crop;
   const float g = h->eg_g, inv_g = h->eg_inv_g;
-  const float mnx = h->eg_min[0], mny = h->eg_min[1], mnz = h->eg_min[2];
   const int dx_ = h->eg_dim[0], dy_ = h->eg_dim[1], dz_ = h->eg_dim[2];
   const double maxd2 = prm.maxd2;
   const float gate_f = (float)maxd2 * 1.0001f;  // pruning bound; the gate itself is the double comparison below
@@ -177,67 +425,73 @@ __global__ __launch_bounds__(256) void k_likelihood_exact(PftParams prm, PftDev 
       const float4 r = d.ref_xyz[j];
       float qx, qy, qz;
       xform(T, r.x, r.y, r.z, qx, qy, qz);
-      float best = INFINITY;
-      uint32_t bi = 0xffffffffu;
-      float4 bt = make_float4(0, 0, 0, 0);
+      EgHit b;
+      b.best = INFINITY;
+      b.bi = 0xffffffffu;
+      b.bt = make_float4(0, 0, 0, 0);
       if (n_crop > 0) {
-        // the query's own cell (not clamped: a query outside the box starts its rings outside)
-        const int cqx = (int)floorf((qx - mnx) * inv_g), cqy = (int)floorf((qy - mny) * inv_g),
-                  cqz = (int)floorf((qz - mnz) * inv_g);
-        // Shells of growing Chebyshev radius rr around the query's cell.  The cells of one (z, y) row are contiguous
-        // in the sorted order, so a row segment costs two loads of cell starts however many cells it spans: rows on the
-        // shell's faces are scanned over their whole x range, inner rows only at their two end cells.  A row whose
-        // cells are all farther than the best distance so far is skipped before anything is loaded (a point in a row
-        // at offset o is at least (|o| - 1) cells away on that axis), and once shell rr is done everything closer than
-        // rr * g has been seen.
-        const float gg = g * 0.9999f;
-        for (int rr = 0; rr <= R; rr++) {
-          for (int oz = -rr; oz <= rr; oz++) {
-            const int cz = cqz + oz;
-            if (cz < 0 || cz >= dz_) continue;
-            const float lz = (float)max(abs(oz) - 1, 0) * gg;
-            for (int oy = -rr; oy <= rr; oy++) {
-              const int cy = cqy + oy;
-              if (cy < 0 || cy >= dy_) continue;
-              const float ly = (float)max(abs(oy) - 1, 0) * gg;
-              const float lyz = ly * ly + lz * lz;
-              const bool face = (abs(oz) == rr) || (abs(oy) == rr);
-              const float lx = face ? 0.0f : (float)max(rr - 1, 0) * gg;
-              if (lyz + lx * lx > fminf(best, gate_f)) continue;
-              const uint32_t row = (uint32_t)((cz * dy_ + cy) * dx_);
-              // face rows: one segment [cqx-rr, cqx+rr]; inner rows: the two cells cqx-rr and cqx+rr
-              const int nseg = (face || rr == 0) ? 1 : 2;
-              for (int sgi = 0; sgi < nseg; sgi++) {
-                int x0, x1;
-                if (nseg == 1) {
-                  x0 = max(cqx - rr, 0);
-                  x1 = min(cqx + rr, dx_ - 1);
-                } else {
-                  x0 = x1 = sgi == 0 ? cqx - rr : cqx + rr;
-                  if (x0 < 0 || x0 >= dx_) continue;
-                }
-                if (x0 > x1) continue;
-                const uint32_t s0 = d.eg_start[row + (uint32_t)x0], s1 = d.eg_start[row + (uint32_t)x1 + 1u];
-                for (uint32_t pos = s0; pos < s1; pos++) {
-                  const float4 p = d.leaf_pts[pos];
-                  const float ex = p.x - qx, ey = p.y - qy, ez = p.z - qz;
-                  const float dd = ex * ex + (ey * ey + ez * ez);  // pointSquaredDist
-                  if (dd <= best) {
-                    const uint32_t idx = d.leaf_order[pos];
-                    if (dd < best || idx < bi) {  // equal distances: the lowest index
-                      best = dd;
-                      bi = idx;
-                      bt = p;
-                    }
-                  }
-                }
-              }
-            }
+        int cqx, cqy, cqz;
+        const bool inside = eg_query_cell(h, qx, qy, qz, cqx, cqy, cqz);
+        uint32_t cnt = EC_NOLIST, slot = 0;
+        if (use_lists && inside) {
+          const uint32_t sl = d.ec_slot[(uint32_t)((cqz * dy_ + cqy) * dx_ + cqx)];
+          if (sl >= 2u && sl != EC_NOLIST) {
+            slot = sl - 2u;
+            cnt = d.ec_count[slot];
           }
-          const float reach = (float)rr * gg;  // everything closer than this has been seen
-          if (best < reach * reach || reach * reach > gate_f) break;
+        }
+        if (DEBUG_NN) {  // list statistics (tools/exact_nn_bench.py): queries, served by a list, candidates walked
+          atomicAdd(&d.hdr->dbg[0], 1ull);
+          if (cnt != EC_NOLIST) {
+            atomicAdd(&d.hdr->dbg[1], 1ull);
+            atomicAdd(&d.hdr->dbg[2], (unsigned long long)cnt);
+          }
+          if (!inside) atomicAdd(&d.hdr->dbg[3], 1ull);
+          int mc = cnt != EC_NOLIST ? (int)cnt : 100000;
+          for (int o = 32; o > 0; o >>= 1) mc = max(mc, __shfl_xor(mc, o));
+          if (lane == __ffsll((long long)__ballot(1)) - 1) {
+            atomicAdd(&d.hdr->dbg[4], 1ull);
+            if (mc < 100000) atomicAdd(&d.hdr->dbg[5], (unsigned long long)mc);
+            else atomicAdd(&d.hdr->dbg[6], 1ull);
+          }
+        }
+        if (cnt != EC_NOLIST) {  // the cell's candidate list holds every possible in-gate nearest neighbour
+          // four candidates in flight per round; entries past the end repeat the last one (harmless: a repeat is
+          // neither closer nor, with the same index, earlier)
+          const float4* list = d.ec_list + d.ec_base[slot];
+          uint32_t bpos = 0xffffffffu;
+          for (uint32_t k = 0; k < cnt; k += 4u) {
+            const float4 c0 = list[k], c1 = list[min(k + 1u, cnt - 1u)], c2 = list[min(k + 2u, cnt - 1u)],
+                         c3 = list[min(k + 3u, cnt - 1u)];
+#define EC_TEST(C)                                                                         \
+  {                                                                                        \
+    const float ex = (C).x - qx, ey = (C).y - qy, ez = (C).z - qz;                         \
+    const float dd = ex * ex + (ey * ey + ez * ez);                                        \
+    const uint32_t pos = __float_as_uint((C).w);                                           \
+    if (dd == b.best && pos != bpos) { /* equal distances (rare): the lowest cloud index */ \
+      if (d.leaf_order[pos] < d.leaf_order[bpos]) bpos = pos;                              \
+    }                                                                                      \
+    const bool lt = dd < b.best;                                                           \
+    b.best = lt ? dd : b.best;                                                             \
+    bpos = lt ? pos : bpos;                                                                \
+  }
+            EC_TEST(c0);
+            EC_TEST(c1);
+            EC_TEST(c2);
+            EC_TEST(c3);
+#undef EC_TEST
+          }
+          if (bpos != 0xffffffffu) {
+            b.bi = d.leaf_order[bpos];
+            b.bt = d.leaf_pts[bpos];
+          }
+        } else {
+          eg_shell_search(d, cqx, cqy, cqz, g, dx_, dy_, dz_, R, gate_f, qx, qy, qz, b);
         }
       }
+      const float best = b.best;
+      const uint32_t bi = b.bi;
+      const float4 bt = b.bt;
       if (DEBUG_NN) {
         const size_t o = (size_t)pi * M + d.ref_perm[j];
         const bool in_gate = bi != 0xffffffffu && (double)best < maxd2;
@@ -277,12 +531,18 @@ __global__ __launch_bounds__(256) void k_likelihood_exact(PftParams prm, PftDev 
 
 void pftk_likelihood_exact(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, bool debug_nn,
                            int num_cus) {
+  const int use_lists = getenv("PFT_EXACT_SHELLS_ONLY") ? 0 : 1;  // 0: the per-query shell search alone (cross-check, A/B timing)
   const uint32_t items = n_particles * p.nchunk;
   uint32_t grid = 8u * (uint32_t)num_cus;
   const uint32_t need = (items + 3u) / 4u;
   if (grid > need) grid = need ? need : 1u;
+  if (use_lists) {
+    hipLaunchKernelGGL(k_ec_mark, dim3(grid), dim3(256), 0, s, p, d, n_particles);
+    hipLaunchKernelGGL(k_ec_slots, dim3(4u * (uint32_t)num_cus), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(k_ec_build, dim3(8u * (uint32_t)num_cus), dim3(256), 0, s, p, d);
+  }
   if (debug_nn)
-    hipLaunchKernelGGL(k_likelihood_exact<true>, dim3(grid), dim3(256), 0, s, p, d, n_particles);
+    hipLaunchKernelGGL(k_likelihood_exact<true>, dim3(grid), dim3(256), 0, s, p, d, n_particles, use_lists);
   else
-    hipLaunchKernelGGL(k_likelihood_exact<false>, dim3(grid), dim3(256), 0, s, p, d, n_particles);
+    hipLaunchKernelGGL(k_likelihood_exact<false>, dim3(grid), dim3(256), 0, s, p, d, n_particles, use_lists);
 }

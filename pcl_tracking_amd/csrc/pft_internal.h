@@ -34,6 +34,8 @@
 #define PFT_POP_THREADS 1024
 #define PFT_SORTED_BUILD_MIN 18000  // cropped points (last iteration) above which the sorted builder is used
 #define PFT_EG_CAP (1u << 21)     // exact-NN mode: grid cells (8 MB of cell starts)
+#define PFT_EC_SLOTS (1u << 19)  // exact-NN mode: candidate lists per iteration (cells hit by queries)
+#define PFT_EC_POOL (1u << 24)   // exact-NN mode: candidate entries of all lists together (16 B each)
 #define PFT_POPM_THREADS 256
 #define PFT_POPM_ITEMS 16   // many-workgroup population path: 4096 particles per workgroup
 #define PFT_POPM_MAX_WGS 256
@@ -91,6 +93,8 @@ struct PftHeader {  // lives in HBM; written by kernels, read by later kernels (
   float eg_g, eg_inv_g, eg_min[3];
   int32_t eg_dim[3];
   uint32_t eg_ncells;
+  uint32_t ec_nslots;           // exact-NN mode: grid cells hit by at least one query this iteration (candidate lists)
+  uint32_t ec_pool_used;        // exact-NN mode: candidate entries allotted so far
   uint32_t p_active;            // KLD variant: current particle_num_ (written by init / k_resample_kld)
   uint32_t kld_k;               // KLD variant: distinct bins of the last resample (diagnostic)
   unsigned long long stat_queries, stat_scanned;
@@ -134,6 +138,11 @@ struct PftDev {  // device pointers (host-side struct, passed by value)
   uint32_t* eg_cnt;          // exact-NN mode: [eg_cap] cell counts / fill cursors
   uint32_t* eg_tile;         // exact-NN mode: per-2048-cell tile sums
   uint32_t eg_cap;           // exact-NN mode: cells available
+  uint32_t* ec_slot;         // exact-NN mode: [eg_cap] 0 = no query in this cell, 1 = hit (before the slots are allotted), 0xffffffff = no list, else list slot + 2
+  uint32_t* ec_cells;        // exact-NN mode: [PFT_EC_SLOTS] cell of every list slot
+  uint32_t* ec_count;        // exact-NN mode: [PFT_EC_SLOTS] candidates of the list (0xffffffff: the pool was full, no list)
+  uint32_t* ec_base;         // exact-NN mode: [PFT_EC_SLOTS] first entry of the list in ec_list
+  float4* ec_list;           // exact-NN mode: [PFT_EC_POOL] candidates {x, y, z, position in leaf_pts}
   uint32_t* kld_table;       // KLD variant: open-addressing table of first occurrences, 2 x pow2(kld_max) entries
   int32_t* kld_bins;         // KLD variant: 6 ints per candidate
   uint32_t* host_stat;  // pinned host memory, device-visible: [0] last n_crop, [1] last octree depth (read by the

@@ -442,8 +442,12 @@ def test_compute_other_iteration_counts(gpu, orc, data, iters):
 
 
 # ---- NearestPairPointCloudCoherence (true nearest neighbour) -----------------------------------
-@pytest.mark.parametrize("M,N,P,maxd", [(256, 6000, 48, 0.1), (513, 20000, 33, 0.1), (64, 900, 20, 0.03), (300, 50000, 16, 0.25)])
-def test_exact_nearest_pair_coherence(gpu, orc, data, M, N, P, maxd):
+@pytest.mark.parametrize("M,N,P,maxd,shells", [(256, 6000, 48, 0.1, False), (513, 20000, 33, 0.1, False), (64, 900, 20, 0.03, False),
+                                               (300, 50000, 16, 0.25, False), (256, 6000, 48, 0.1, True), (300, 50000, 16, 0.25, True)])
+def test_exact_nearest_pair_coherence(gpu, orc, data, M, N, P, maxd, shells, monkeypatch):
+    """both search paths of pft_exact_nn.hip: per-cell candidate lists (default) and the per-query shell search alone"""
+    if shells:
+        monkeypatch.setenv("PFT_EXACT_SHELLS_ONLY", "1")
     model = scene.make_model(M, seed=900 + M)
     cloud = data["scene"][:N]
     o = orc.Tracker(orc.default_config(particle_num=P, threads=0, emulate_pcl_alloc=0, exact_nearest=1, max_distance=maxd))
@@ -574,3 +578,52 @@ def test_eval_weights_adversarial_clouds(gpu, orc, data, kind, monkeypatch):
         np.testing.assert_array_equal(G["nn_idx"], O["nn_idx"])
         np.testing.assert_array_equal(G["nn_d2"], O["nn_d2"])
         assert ulp_diff(G["raw"], O["raw"]).max() <= 1
+
+
+@pytest.mark.parametrize("kind", ["lattice", "duplicates"])
+def test_exact_nearest_ties_take_the_lowest_index(gpu, orc, data, kind):
+    """clouds with many equal distances (points on a 1 cm lattice, 40 positions repeated 150 times each): the true nearest
+    neighbour is the lowest cloud index among the closest points, whatever order the grid cells hold them in"""
+    rng = np.random.default_rng(11)
+    gt = np.array(data["gt"][:3], np.float32)
+    n = 6000
+    c = np.zeros(n, scene.POINT_DTYPE)
+    c["w"] = 1.0
+    c["rgba"] = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    if kind == "lattice":
+        xyz = np.round(rng.uniform(-0.12, 0.12, (n, 3)) / 0.01) * 0.01 + np.round(gt / 0.01) * 0.01
+    else:
+        xyz = (rng.uniform(-0.2, 0.2, (40, 3)) + gt)[rng.integers(0, 40, n)]
+    xyz = xyz.astype(np.float32)
+    c["x"], c["y"], c["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    P = 24
+    o = orc.Tracker(orc.default_config(particle_num=P, threads=0, emulate_pcl_alloc=0, exact_nearest=1, max_distance=0.1))
+    g = gpu.ParticleFilterTracker(seed=1)
+    g.setParticleNum(P)
+    coh = gpu.NearestPairPointCloudCoherence()
+    coh.addPointCoherence(gpu.DistanceCoherence())
+    hc = gpu.HSVColorCoherence()
+    hc.setWeight(0.1)
+    coh.addPointCoherence(hc)
+    coh.setMaximumDistance(0.1)
+    g.setCloudCoherence(coh)
+    # model points on the same lattice: queries at identity rotation are equidistant from several cloud points
+    m = data["model"][:400].copy()
+    for k in ("x", "y", "z"):
+        m[k] = (np.round(m[k] / 0.005) * 0.005).astype(np.float32)
+    for ref, tr, inp in ((g.setReferenceCloud, g.setTrans, g.setInputCloud), (o.set_reference, o.set_trans, o.set_input)):
+        ref(m)
+        tr(scene.initial_trans())
+        inp(c)
+    p = particles_around(data["gt"], P, 5, sig_t=0.02, sig_r=0.0)
+    for k in ("roll", "pitch", "yaw"):
+        p[k] = 0.0
+    for k, v in zip(("x", "y", "z"), np.round(gt / 0.005) * 0.005):
+        p[k][: P // 2] = np.float32(v)  # half of the particles exactly on the lattice
+    G = g.evalWeights(p, want_nn=True)
+    O = o.eval_weights(p, want_nn=True, mats=g.debugPoseToMatrix(p))
+    gate = O["nn_d2"].astype(np.float64) < 0.01
+    assert gate.any()
+    np.testing.assert_array_equal(G["nn_idx"][gate], O["nn_idx"][gate])
+    np.testing.assert_array_equal(G["nn_d2"][gate], O["nn_d2"][gate])
+    assert ulp_diff(G["raw"], O["raw"]).max() <= 1

@@ -37,3 +37,13 @@ for exact in (False, True):
     print("%s: %.3f ms/frame (with events)  grid/octree %.1f us  likelihood %.1f us per launch" % (
         "exact NN " if exact else "approx NN", dt * 1e3, pr["octree"][0] / pr["octree"][1] * 1e3,
         pr["likelihood"][0] / pr["likelihood"][1] * 1e3))
+    if exact:
+        import ctypes as C
+        import numpy as np
+        p = t.getParticles()
+        t.evalWeights(p, want_nn=True)  # the debug variant counts list use (first call: counters start at zero?)
+        dbg = np.zeros(32, np.uint64)
+        t._check(t._L.pft_debug_get_descent_stats(t._h, dbg.ctypes.data_as(C.c_void_p)))
+        q, served, walked, outside, waves, wmax, wfall = [int(v) for v in dbg[:7]]
+        print("  queries %d, served by a list %.4f, mean list %.1f, outside the grid %d; per wave: max list %.1f, waves with a shell-search lane %.4f"
+              % (q, served / max(q, 1), walked / max(served, 1), outside, wmax / max(waves - wfall, 1), wfall / max(waves, 1)))
