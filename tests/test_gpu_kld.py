@@ -86,6 +86,32 @@ def test_kld_tracker_tracks_like_oracle(gpu, orc):
     assert len(set(counts)) >= 1
 
 
+def test_kld_tracker_with_the_exact_nearest_pair_coherence(gpu, orc):
+    """both optional parts together: the device-resident particle count of the KLD variant sizes the candidate-list
+    kernels of the NearestPairPointCloudCoherence mode"""
+    model, cloud = scene.make_model(512), scene.make_scene(20000)
+    g = gpu.make_reference_tracker(particle_num=300, seed=9, kld=True)
+    coh = gpu.NearestPairPointCloudCoherence()
+    coh.addPointCoherence(gpu.DistanceCoherence())
+    hc = gpu.HSVColorCoherence()
+    hc.setWeight(0.1)
+    coh.addPointCoherence(hc)
+    coh.setMaximumDistance(0.1)
+    g.setCloudCoherence(coh)
+    o = orc.Tracker(orc.default_config(particle_num=300, seed=9, threads=0, emulate_pcl_alloc=0, kld_adaptive=1, exact_nearest=1))
+    for ref, tr, inp in ((g.setReferenceCloud, g.setTrans, g.setInputCloud), (o.set_reference, o.set_trans, o.set_input)):
+        ref(model)
+        tr(scene.initial_trans())
+        inp(cloud)
+    for f in range(2):
+        g.compute()
+        assert o.compute() == 0
+        assert len(g.getParticles()) == len(o.get_particles())
+        rg, ro = g.getResult(), o.get_result()
+        for k in KEYS:
+            assert abs(float(rg[k]) - float(ro[k])) < 1e-4, (f, k, rg, ro)
+
+
 def test_kld_tracker_rejects_sharding(gpu):
     from pcl_tracking_amd._lib import PftError
 
