@@ -25,6 +25,8 @@ struct BuildSh {
   uint32_t gidx[PFT_MAX_GROW], gshift[PFT_MAX_GROW], gold[PFT_MAX_GROW];
   double gmin[PFT_MAX_GROW + 1][3];
   uint32_t lvl[PFT_MAX_DEPTH + 3];
+  // dense top levels (build_tree): per level <= J the occupancy bits in Morton order, their popcount prefix, node counts
+  uint32_t dn_bits[PFT_JUMP_MAX_LEVEL + 1][128], dn_pref[PFT_JUMP_MAX_LEVEL + 1][128], dn_cnt[PFT_JUMP_MAX_LEVEL + 1];
 };
 
 // first point: box = p +- res/2, then getKeyBitSize() pads it to depth 1 (side 2*res - eps)
@@ -221,6 +223,13 @@ __device__ __forceinline__ bool build_tree(const PftParams& prm, const PftDev& d
   const double res = prm.res, inv_res = 1.0 / prm.res;
   const int D = S.depth, ngrow = S.ngrow;
   Store st(d);
+  // direct-index table of the level-J nodes for the likelihood kernel's fast descent; the levels above J are built from
+  // the occupancy bits of the level-J cells (below), which the key phase records as it goes
+  const int J = (D >= 4 && D <= PFT_TABLE_MAX_DEPTH) ? (D - 1 < PFT_JUMP_MAX_LEVEL ? D - 1 : PFT_JUMP_MAX_LEVEL) : 0;
+  if (J > 0) {
+    for (uint32_t i = tid; i < 128u; i += nt) S.dn_bits[J][i] = 0u;
+    __syncthreads();
+  }
 
   // ---- keys: genOctreeKeyforPoint at insertion time, shifted into the final key frame ----
   st.each(n, [&](uint32_t i, key_t& key, uint32_t& node) {
@@ -254,28 +263,99 @@ __device__ __forceinline__ bool build_tree(const PftParams& prm, const PftDev& d
 
   STAMP(2);
   uint32_t* W = LDSW ? lds_words : d.words;
-  // direct-index table of the level-J nodes for the likelihood kernel's fast descent
-  const int J = (D >= 4 && D <= PFT_TABLE_MAX_DEPTH) ? (D - 1 < PFT_JUMP_MAX_LEVEL ? D - 1 : PFT_JUMP_MAX_LEVEL) : 0;
   if (J > 0) {
     uint32_t* jz = reinterpret_cast<uint32_t*>(d.jump);
     for (uint32_t j = tid; j < (1u << (3 * J - 1)); j += nt) jz[j] = 0u;
   }
-  if (tid == 0) {
-    W[0] = 0;
-    S.lvl[0] = 0;
-    S.lvl[1] = 1;
-    S.jump = J;
+  if (tid == 0) S.jump = J;
+  // ---- levels 0 .. J-1 without a pass over the points per level: near the root thousands of points share a node, so
+  // the occupancy of the level-J cells (at most 8^4) is recorded once in a bit array in Morton order; the child mask
+  // of a level-(l-1) node is then literally byte i of the level-l bit array, a node's index inside its level is the
+  // rank of its bit, and its children start at the rank of its first child's bit ----
+  int l0 = 0;
+  if (J > 0) {
+    uint32_t (*dn_bits)[128] = S.dn_bits;
+    uint32_t (*dn_pref)[128] = S.dn_pref;
+    uint32_t* dn_cnt = S.dn_cnt;
+    st.each(n, [&](uint32_t, key_t& key, uint32_t& node) {  // Morton index of the point's level-J cell; its occupancy bit
+      uint32_t mj = 0;
+      for (int l = 0; l < J; l++) mj = (mj << 3) | key_child<key_t, B>(key, D - 1 - l);
+      node = mj;
+      const uint32_t bt = 1u << (mj & 31u);
+      if (!(dn_bits[J][mj >> 5] & bt)) atomicOr(&dn_bits[J][mj >> 5], bt);
+    });
+    __syncthreads();
+    for (int l = J - 1; l >= 0; l--) {  // bit i of level l = "byte i of level l + 1 is not zero" (at most 512 bits: one ballot per wave)
+      const uint32_t nbits = 1u << (3 * l);
+      const bool pred = tid < nbits && ((dn_bits[l + 1][tid >> 2] >> (8u * (tid & 3u))) & 0xffu) != 0u;
+      const unsigned long long m = __ballot(pred);
+      if (lane_id() == 0 && (uint32_t)wave_id() * 64u < ((nbits + 63u) & ~63u)) {
+        dn_bits[l][2 * wave_id()] = (uint32_t)m;
+        dn_bits[l][2 * wave_id() + 1] = (uint32_t)(m >> 32);
+      }
+      __syncthreads();
+    }
+    if (wave_id() <= J) {  // one wave per level: exclusive popcount prefix over the level's (at most 128) words
+      const int l = wave_id(), ln = lane_id();
+      const uint32_t nwords = ((1u << (3 * l)) + 31u) >> 5;
+      const uint32_t c0 = (uint32_t)ln < nwords ? __popc(dn_bits[l][ln]) : 0u;
+      const uint32_t c1 = (uint32_t)ln + 64u < nwords ? __popc(dn_bits[l][ln + 64]) : 0u;
+      const uint32_t i0 = wave_incl_scan(c0);
+      const uint32_t t0 = (uint32_t)__shfl((int)i0, 63);
+      const uint32_t i1 = wave_incl_scan(c1);
+      dn_pref[l][ln] = i0 - c0;
+      dn_pref[l][ln + 64] = t0 + i1 - c1;
+      if (ln == 63) dn_cnt[l] = t0 + i1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      S.lvl[0] = 0;
+      for (int l = 0; l <= J; l++) S.lvl[l + 1] = S.lvl[l] + dn_cnt[l];
+    }
+    __syncthreads();
+    const uint32_t top_end = S.lvl[J + 1];
+    if (LDSW && top_end + 2 > lds_words_cap) return false;  // uniform: not even the top levels fit (tiny LDS share)
+    if (top_end + 2 > d.max_words) {
+      if (tid == 0) S.err |= 1u;
+    } else {
+#define DN_RANK(l, i) (dn_pref[l][(i) >> 5] + __popc(dn_bits[l][(i) >> 5] & ((1u << ((i) & 31u)) - 1u)))
+      {  // node words of the levels below J: 1 + 8 + 64 + 512 candidates, one thread each
+        int l = 0;
+        uint32_t i = tid;
+        while (l < J && i >= (1u << (3 * l))) {
+          i -= 1u << (3 * l);
+          l++;
+        }
+        if (l < J && ((dn_bits[l][i >> 5] >> (i & 31u)) & 1u)) {
+          const uint32_t mask = (dn_bits[l + 1][i >> 2] >> (8u * (i & 3u))) & 0xffu;
+          const uint32_t base = S.lvl[l + 1] + DN_RANK(l + 1, 8u * i);
+          W[S.lvl[l] + DN_RANK(l, i)] = mask | (base << 8);
+        }
+      }
+      for (uint32_t j = S.lvl[J] + tid; j < top_end; j += nt) W[j] = 0;
+      const uint32_t lj = S.lvl[J];
+      st.each(n, [&](uint32_t, key_t&, uint32_t& node) { node = lj + DN_RANK(J, node); });
+#undef DN_RANK
+    }
+    __syncthreads();
+    l0 = J;
+  } else {
+    if (tid == 0) {
+      W[0] = 0;
+      S.lvl[0] = 0;
+      S.lvl[1] = 1;
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
   // ---- levels ----
   unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, t0_, t1_;
-  for (int l = 0; l < D; l++) {
+  for (int l = l0; l < D && !S.err; l++) {
     const int bit = D - 1 - l;
     t0_ = wall_clock64();
     const uint32_t lvl_first = S.lvl[l];
     st.each(n, [&](uint32_t, key_t& key, uint32_t& node) {
-      if (l > 0) {  // move to the level-l node chosen by the previous level's bits
+      if (l > l0) {  // move to the level-l node chosen by the previous level's bits
         uint32_t w = W[node];
         uint32_t cp = key_child<key_t, B>(key, bit + 1);
         node = (w >> 8) + __popc(w & 0xffu & ((1u << cp) - 1u));
@@ -373,12 +453,16 @@ __device__ __forceinline__ bool build_tree(const PftParams& prm, const PftDev& d
   st.each(n, [&](uint32_t i, key_t& key, uint32_t& node) { TMP[W[node] + (uint32_t)key] = i; });
   __syncthreads();
   STAMP(5);
+  // (the cloud pointer is re-read from the kernel arguments here: carrying the per-thread address computed for the key
+  // phase through all the levels costs two VGPRs that the 14-points-per-thread variant does not have)
+  const float4* pts_late = d.crop_pts;
+  asm volatile("" : "+s"(pts_late));
   st.each(n, [&](uint32_t i, key_t&, uint32_t& node) {
     const uint32_t s = W[node], e = W[node + 1];
     uint32_t rank = 0;
     for (uint32_t k = s; k < e; k++) rank += TMP[k] < i ? 1u : 0u;
     d.leaf_order[s + rank] = i;
-    d.leaf_pts[s + rank] = pts[i];
+    d.leaf_pts[s + rank] = pts_late[i];
   });
   STAMP(6);
   const uint32_t n_words = leaf_start + n_leaves + 1;
@@ -525,8 +609,8 @@ __global__ __launch_bounds__(PFT_BUILD_THREADS) void k_octree_build(PftParams pr
 
 void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d) {
   static bool attr_set = false;
-  // static LDS of the kernel (BuildSh) is ~2.6 KB: leave 4 KB out of the dynamic request
-  const uint32_t lds = ((uint32_t)pftk_max_lds_bytes() - 4096u) & ~15u;
+  // static LDS of the kernel (BuildSh ~2.6 KB, the dense top-level arrays 5 KB): leave 10 KB out of the dynamic request
+  const uint32_t lds = ((uint32_t)pftk_max_lds_bytes() - 10240u) & ~15u;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_octree_build), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lds);
