@@ -667,7 +667,7 @@ static void stage_aabb(pft_tracker* t, const PftDev& d, uint32_t np, bool finali
 }
 // A4, A5, A6+A7
 static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32_t np, bool debug_nn,
-                                         bool bbox_from_partials) {
+                                         bool bbox_from_partials, bool keep_point_keys = false) {
   {
     ProfScope ps(t, PFT_K_CROP);
     pftk_crop(t->stream, t->prm, d, bbox_from_partials);
@@ -683,6 +683,8 @@ static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32
   }
   {
     ProfScope ps(t, PFT_K_OCTREE);
+    PftDev db = d;
+    if (!keep_point_keys) db.pt_key = nullptr;  // the per-point keys are a test hook (pft_debug_get_point_keys after pft_eval_weights)
     // the single-workgroup builder is fastest for small crops, the sorted many-workgroup builder scales; both
     // are correct for any size.  The choice uses the crop size / depth of the PREVIOUS iteration, read from
     // pinned memory without synchronising.
@@ -700,10 +702,10 @@ static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32
       // if the tree turned out deeper than the passes cover)
       int npass = last_depth > 0u ? (int)((3u * (last_depth + 1u) + 7u) / 8u) : 8;
       if (npass > 8) npass = 8;
-      pftk_octree_sorted(t->stream, t->prm, d, t->sort, d.N, npass);
+      pftk_octree_sorted(t->stream, t->prm, db, t->sort, d.N, npass);
     }
     else
-      pftk_octree(t->stream, t->prm, d);
+      pftk_octree(t->stream, t->prm, db);
   }
   {
     ProfScope ps(t, PFT_K_LIKELIHOOD);
@@ -917,7 +919,7 @@ extern "C" int pft_eval_weights(pft_tracker* t, const pft_particle* particles, s
   HIPCHK(t, hipMemsetAsync(&t->d_hdr->stat_queries, 0, (2 + 32) * sizeof(unsigned long long), t->stream));
   pftk_pose_to_matrix(t->stream, t->d_dbg_part, (uint32_t)P, t->d_mats);
   stage_aabb(t, d, (uint32_t)P, false);
-  stage_crop_octree_likelihood(t, d, (uint32_t)P, want_nn, true);
+  stage_crop_octree_likelihood(t, d, (uint32_t)P, want_nn, true, true);
   pftk_finalize_raw(t->stream, t->prm, d, (uint32_t)P, t->d_dbg_f);
   if (raw_w) HIPCHK(t, hipMemcpyAsync(raw_w, t->d_dbg_f, P * sizeof(float), hipMemcpyDeviceToHost, t->stream));
   if (nn_idx) HIPCHK(t, hipMemcpyAsync(nn_idx, t->d_nn_idx, pairs * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));

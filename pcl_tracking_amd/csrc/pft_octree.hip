@@ -90,40 +90,54 @@ __device__ __forceinline__ bool box_violates(float x, float y, float z, const do
 }
 
 // Replay of the growth sequence.  The box after the first few dozen points usually contains everything,
-// so: (a) wave 0 alone handles the growth events among the first 64 points (one ballot per event, no
-// workgroup barrier); (b) the workgroup then looks for later violators with a per-thread AABB quick reject;
-// each remaining event costs one min-index reduction.
+// so: (a) wave 0 alone handles the growth events among the first 1024 points (16 chunks of 64 held in registers, one
+// ballot per event, no workgroup barrier); (b) the workgroup then looks for later violators with a per-thread AABB
+// quick reject; each remaining event costs one min-index reduction.
+#define PFT_REPLAY_HEAD 1024u
 __device__ __forceinline__ void box_replay(BuildSh& S, const float4* __restrict__ pts, uint32_t n, double res) {
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
-  const uint32_t head = n < 64u ? n : 64u;
+  const uint32_t head = n < PFT_REPLAY_HEAD ? n : PFT_REPLAY_HEAD;
   if (tid < WAVE) {
-    const float4 p = tid < n ? pts[tid] : pts[0];
+    float4 q[PFT_REPLAY_HEAD / WAVE];
+#pragma unroll
+    for (uint32_t c = 0; c < PFT_REPLAY_HEAD / WAVE; c++) q[c] = pts[min(c * WAVE + tid, n - 1u)];
     uint32_t cur = 1;
-    for (;;) {
-      const double mn[3] = {S.mn[0], S.mn[1], S.mn[2]};
-      const double mx[3] = {S.mx[0], S.mx[1], S.mx[2]};
-      const bool viol = tid >= cur && tid < head && box_violates(p.x, p.y, p.z, mn, mx);
-      const unsigned long long bal = __ballot(viol);
-      if (!bal) break;
-      const int f = __ffsll((long long)bal) - 1;
-      const float4 pf = make_float4(__shfl(p.x, f), __shfl(p.y, f), __shfl(p.z, f), 0.0f);
-      if (tid == 0) box_grow(S, pf, (uint32_t)f, res);
-      cur = (uint32_t)f + 1u;
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // lane 0's LDS writes -> the wave's next reads
-      __builtin_amdgcn_wave_barrier();
-      if (S.err) break;
+    bool stop = false;
+#pragma unroll
+    for (uint32_t c = 0; c < PFT_REPLAY_HEAD / WAVE; c++) {
+      const uint32_t gi = c * WAVE + tid;
+      const float4 p = q[c];
+      while (!stop) {
+        const double mn[3] = {S.mn[0], S.mn[1], S.mn[2]};
+        const double mx[3] = {S.mx[0], S.mx[1], S.mx[2]};
+        const bool viol = gi >= cur && gi < head && box_violates(p.x, p.y, p.z, mn, mx);
+        const unsigned long long bal = __ballot(viol);
+        if (!bal) break;
+        const int f = __ffsll((long long)bal) - 1;
+        const float4 pf = make_float4(__shfl(p.x, f), __shfl(p.y, f), __shfl(p.z, f), 0.0f);
+        if (tid == 0) box_grow(S, pf, c * WAVE + (uint32_t)f, res);
+        cur = c * WAVE + (uint32_t)f + 1u;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // lane 0's LDS writes -> the wave's next reads
+        __builtin_amdgcn_wave_barrier();
+        if (S.err) stop = true;
+      }
     }
     if (tid == 0) S.cur = head;
   }
   __syncthreads();
-  if (S.err || n <= 64u) return;
-  // (b) points 64.. : thread-local AABB of the thread's strided points
+  if (S.err || n <= PFT_REPLAY_HEAD) return;
+  // (b) the points after the head: thread-local AABB of the thread's strided points
   float lmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, lmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (uint32_t i = 64u + tid; i < n; i += nt) {
-    const float4 p = pts[i];
-    lmn[0] = fminf(lmn[0], p.x); lmx[0] = fmaxf(lmx[0], p.x);
-    lmn[1] = fminf(lmn[1], p.y); lmx[1] = fmaxf(lmx[1], p.y);
-    lmn[2] = fminf(lmn[2], p.z); lmx[2] = fmaxf(lmx[2], p.z);
+  for (uint32_t i0 = PFT_REPLAY_HEAD + tid; i0 < n; i0 += 8u * nt) {  // eight loads in flight per round (one workgroup: latency-bound)
+    float4 q[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; k++) q[k] = pts[min(i0 + k * nt, n - 1u)];  // (a repeated point changes no minimum)
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; k++) {
+      lmn[0] = fminf(lmn[0], q[k].x); lmx[0] = fmaxf(lmx[0], q[k].x);
+      lmn[1] = fminf(lmn[1], q[k].y); lmx[1] = fmaxf(lmx[1], q[k].y);
+      lmn[2] = fminf(lmn[2], q[k].z); lmx[2] = fmaxf(lmx[2], q[k].z);
+    }
   }
   for (;;) {
     const uint32_t cur = S.cur;
@@ -131,7 +145,7 @@ __device__ __forceinline__ void box_replay(BuildSh& S, const float4* __restrict_
     const double mx[3] = {S.mx[0], S.mx[1], S.mx[2]};
     uint32_t first = 0xffffffffu;
     if (box_violates(lmn[0], lmn[1], lmn[2], mn, mx) || box_violates(lmx[0], lmx[1], lmx[2], mn, mx)) {
-      uint32_t i0 = 64u + tid;
+      uint32_t i0 = PFT_REPLAY_HEAD + tid;
       if (i0 < cur) i0 += ((cur - i0 + nt - 1) / nt) * nt;
       for (uint32_t i = i0; i < n; i += nt) {
         const float4 p = pts[i];
@@ -232,10 +246,14 @@ __device__ __forceinline__ bool build_tree(const PftParams& prm, const PftDev& d
   }
 
   // ---- keys: genOctreeKeyforPoint at insertion time, shifted into the final key frame ----
+  const uint32_t last_grow = ngrow > 0 ? S.gidx[ngrow - 1] : 0u;
   st.each(n, [&](uint32_t i, key_t& key, uint32_t& node) {
     float4 p = pts[i];
-    int e = 0;
-    while (e < ngrow && S.gidx[e] <= i) e++;
+    int e = ngrow;  // growth epoch of the point: almost every point comes after the last growth event
+    if (ngrow > 0 && i < last_grow) {
+      e = 0;
+      while (e < ngrow && S.gidx[e] <= i) e++;
+    }
     // (unsigned)((p - min) / res) in double, as genOctreeKeyforPoint: the product with 1/res agrees with
     // the correctly rounded quotient to ~1e-13, so it is used unless it lands within 1e-6 of an integer
     const double tq[3] = {(double)p.x - S.gmin[e][0], (double)p.y - S.gmin[e][1], (double)p.z - S.gmin[e][2]};
@@ -254,9 +272,11 @@ __device__ __forceinline__ bool build_tree(const PftParams& prm, const PftDev& d
       if (sh & 2u) ky += 1u << od;
       if (sh & 4u) kz += 1u << od;
     }
-    d.pt_key[3 * (size_t)i + 0] = kx;  // kept for the debug hook pft_debug_get_point_keys
-    d.pt_key[3 * (size_t)i + 1] = ky;
-    d.pt_key[3 * (size_t)i + 2] = kz;
+    if (d.pt_key) {  // (workgroup-uniform) test hook pft_debug_get_point_keys; null in pft_compute
+      d.pt_key[3 * (size_t)i + 0] = kx;
+      d.pt_key[3 * (size_t)i + 1] = ky;
+      d.pt_key[3 * (size_t)i + 2] = kz;
+    }
     key = ((key_t)kx << (2 * B)) | ((key_t)ky << B) | (key_t)kz;
     node = 0;
   });

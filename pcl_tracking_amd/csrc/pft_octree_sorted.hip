@@ -244,9 +244,11 @@ __global__ void k_so_keys(PftParams prm, PftDev d, SortBufs sb, uint32_t n_pad) 
     if (sh & 2u) kk[1] += 1u << od;
     if (sh & 4u) kk[2] += 1u << od;
   }
-  d.pt_key[3 * (size_t)i + 0] = kk[0];
-  d.pt_key[3 * (size_t)i + 1] = kk[1];
-  d.pt_key[3 * (size_t)i + 2] = kk[2];
+  if (d.pt_key) {  // test hook pft_debug_get_point_keys; null in pft_compute
+    d.pt_key[3 * (size_t)i + 0] = kk[0];
+    d.pt_key[3 * (size_t)i + 1] = kk[1];
+    d.pt_key[3 * (size_t)i + 2] = kk[2];
+  }
   unsigned long long code = 0;
   for (int b = D - 1; b >= 0; b--)
     code = (code << 3) | (unsigned long long)((((kk[0] >> b) & 1u) << 2) | (((kk[1] >> b) & 1u) << 1) | ((kk[2] >> b) & 1u));

@@ -1,5 +1,5 @@
 """In-kernel timestamps (wall_clock64, 100 MHz) of the two single-workgroup kernels at the bench workload: octree build
-phases and population-stage phases.  Usage: python tools/ticks.py [particles]"""
+phases and population-stage phases.  Usage: python tools/ticks.py [particles] [frames]"""
 import ctypes as C
 import os
 import sys
@@ -10,12 +10,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pcl_tracking_amd import scene, tracker  # noqa: E402
 
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+FRAMES = int(sys.argv[2]) if len(sys.argv) > 2 else 10  # bench.py loops one frame: after ~200 the crop has grown to ~13 500 points
 model, cloud = scene.make_model(2048), scene.make_scene(50000)
 t = tracker.make_reference_tracker(particle_num=P, seed=1)
 t.setReferenceCloud(model)
 t.setTrans(scene.initial_trans())
 t.setInputCloud(cloud)
-for i in range(10):
+for i in range(FRAMES):
     t.compute()
 t.synchronize()
 p = t.getParticles()
