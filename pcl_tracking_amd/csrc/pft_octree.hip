@@ -283,10 +283,6 @@ __device__ __forceinline__ bool build_tree(const PftParams& prm, const PftDev& d
 
   STAMP(2);
   uint32_t* W = LDSW ? lds_words : d.words;
-  if (J > 0) {
-    uint32_t* jz = reinterpret_cast<uint32_t*>(d.jump);
-    for (uint32_t j = tid; j < (1u << (3 * J - 1)); j += nt) jz[j] = 0u;
-  }
   if (tid == 0) S.jump = J;
   // ---- levels 0 .. J-1 without a pass over the points per level: near the root thousands of points share a node, so
   // the occupancy of the level-J cells (at most 8^4) is recorded once in a bit array in Morton order; the child mask
@@ -353,6 +349,18 @@ __device__ __forceinline__ bool build_tree(const PftParams& prm, const PftDev& d
         }
       }
       for (uint32_t j = S.lvl[J] + tid; j < top_end; j += nt) W[j] = 0;
+      // the likelihood kernel's direct-index table of the level-J nodes: cell (cx, cy, cz) -> node - first node + 1, 0 = empty
+      for (uint32_t i = tid; i < (1u << (3 * J)); i += nt) {
+        uint32_t cx = 0, cy = 0, cz = 0;
+        for (int b = 0; b < J; b++) {  // digit b (from the leaf side) of the Morton index
+          const uint32_t dg = (i >> (3 * b)) & 7u;
+          cx |= (dg >> 2) << b;
+          cy |= ((dg >> 1) & 1u) << b;
+          cz |= (dg & 1u) << b;
+        }
+        const bool occ = (dn_bits[J][i >> 5] >> (i & 31u)) & 1u;
+        d.jump[cx | (cy << J) | (cz << (2 * J))] = occ ? (uint16_t)(DN_RANK(J, i) + 1u) : (uint16_t)0;
+      }
       const uint32_t lj = S.lvl[J];
       st.each(n, [&](uint32_t, key_t&, uint32_t& node) { node = lj + DN_RANK(J, node); });
 #undef DN_RANK
@@ -373,18 +381,11 @@ __device__ __forceinline__ bool build_tree(const PftParams& prm, const PftDev& d
   for (int l = l0; l < D && !S.err; l++) {
     const int bit = D - 1 - l;
     t0_ = wall_clock64();
-    const uint32_t lvl_first = S.lvl[l];
     st.each(n, [&](uint32_t, key_t& key, uint32_t& node) {
       if (l > l0) {  // move to the level-l node chosen by the previous level's bits
         uint32_t w = W[node];
         uint32_t cp = key_child<key_t, B>(key, bit + 1);
         node = (w >> 8) + __popc(w & 0xffu & ((1u << cp) - 1u));
-      }
-      if (l == J && J > 0) {  // every point of a node stores the same value
-        const uint32_t sh = (uint32_t)(D - J), mk = (1u << J) - 1u;
-        const uint32_t cx = (uint32_t)(key >> (2 * B + sh)) & mk, cy = (uint32_t)(key >> (B + sh)) & mk,
-                       cz = (uint32_t)(key >> sh) & mk;
-        d.jump[cx | (cy << J) | (cz << (2 * J))] = (uint16_t)(node - lvl_first + 1u);
       }
       // near the root thousands of points share a word: test first, so only the first arrivals pay for the
       // (same-address, serialised) LDS atomic
@@ -473,16 +474,11 @@ __device__ __forceinline__ bool build_tree(const PftParams& prm, const PftDev& d
   st.each(n, [&](uint32_t i, key_t& key, uint32_t& node) { TMP[W[node] + (uint32_t)key] = i; });
   __syncthreads();
   STAMP(5);
-  // (the cloud pointer is re-read from the kernel arguments here: carrying the per-thread address computed for the key
-  // phase through all the levels costs two VGPRs that the 14-points-per-thread variant does not have)
-  const float4* pts_late = d.crop_pts;
-  asm volatile("" : "+s"(pts_late));
   st.each(n, [&](uint32_t i, key_t&, uint32_t& node) {
     const uint32_t s = W[node], e = W[node + 1];
     uint32_t rank = 0;
     for (uint32_t k = s; k < e; k++) rank += TMP[k] < i ? 1u : 0u;
-    d.leaf_order[s + rank] = i;
-    d.leaf_pts[s + rank] = pts_late[i];
+    d.leaf_order[s + rank] = i;  // (k_leaf_gather copies the point records: one CU's bandwidth is better spent elsewhere)
   });
   STAMP(6);
   const uint32_t n_words = leaf_start + n_leaves + 1;
@@ -627,6 +623,14 @@ __global__ __launch_bounds__(PFT_BUILD_THREADS) void k_octree_build(PftParams pr
   }
 }
 
+// leaf-ordered point records for the likelihood kernel's leaf scan: leaf_pts[pos] = crop_pts[leaf_order[pos]]
+__global__ __launch_bounds__(256) void k_leaf_gather(PftDev d) {
+  const PftHeader* hdr = d.hdr;
+  const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
+  if (hdr->error || hdr->depth <= 0 || pos >= hdr->n_crop) return;
+  d.leaf_pts[pos] = d.crop_pts[d.leaf_order[pos]];
+}
+
 void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d) {
   static bool attr_set = false;
   // static LDS of the kernel (BuildSh ~2.6 KB, the dense top-level arrays 5 KB): leave 10 KB out of the dynamic request
@@ -637,4 +641,6 @@ void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d) {
     attr_set = true;
   }
   hipLaunchKernelGGL(k_octree_build, dim3(1), dim3(PFT_BUILD_THREADS), lds, s, p, d, lds);
+  // at most PFT_SORTED_BUILD_MIN-ish points reach this builder in practice, but any crop (<= N) is legal
+  hipLaunchKernelGGL(k_leaf_gather, dim3((d.N + 255u) / 256u ? (d.N + 255u) / 256u : 1u), dim3(256), 0, s, d);
 }
