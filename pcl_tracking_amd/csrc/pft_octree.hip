@@ -97,19 +97,36 @@ __device__ __forceinline__ bool box_violates(float x, float y, float z, const do
 __device__ __forceinline__ void box_replay(BuildSh& S, const float4* __restrict__ pts, uint32_t n, double res) {
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   const uint32_t head = n < PFT_REPLAY_HEAD ? n : PFT_REPLAY_HEAD;
+  // (b), first half: thread-local AABB of the thread's strided points after the head -- done by the waves that have
+  // nothing to do while wave 0 replays the head
+  float lmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, lmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  const uint32_t wt = tid - WAVE, ws = nt - WAVE;  // the tail is strided over the waves other than wave 0
+  auto local_aabb = [&]() {
+    for (uint32_t i0 = PFT_REPLAY_HEAD + wt; i0 < n; i0 += 8u * ws) {  // eight loads in flight per round (latency-bound)
+      float4 q[8];
+#pragma unroll
+      for (uint32_t k = 0; k < 8u; k++) q[k] = pts[min(i0 + k * ws, n - 1u)];  // (a repeated point changes no minimum)
+#pragma unroll
+      for (uint32_t k = 0; k < 8u; k++) {
+        lmn[0] = fminf(lmn[0], q[k].x); lmx[0] = fmaxf(lmx[0], q[k].x);
+        lmn[1] = fminf(lmn[1], q[k].y); lmx[1] = fmaxf(lmx[1], q[k].y);
+        lmn[2] = fminf(lmn[2], q[k].z); lmx[2] = fmaxf(lmx[2], q[k].z);
+      }
+    }
+  };
+  if (tid >= WAVE) local_aabb();
   if (tid < WAVE) {
     float4 q[PFT_REPLAY_HEAD / WAVE];
 #pragma unroll
     for (uint32_t c = 0; c < PFT_REPLAY_HEAD / WAVE; c++) q[c] = pts[min(c * WAVE + tid, n - 1u)];
     uint32_t cur = 1;
     bool stop = false;
+    double mn[3] = {S.mn[0], S.mn[1], S.mn[2]}, mx[3] = {S.mx[0], S.mx[1], S.mx[2]};  // re-read only after an event
 #pragma unroll
     for (uint32_t c = 0; c < PFT_REPLAY_HEAD / WAVE; c++) {
       const uint32_t gi = c * WAVE + tid;
       const float4 p = q[c];
       while (!stop) {
-        const double mn[3] = {S.mn[0], S.mn[1], S.mn[2]};
-        const double mx[3] = {S.mx[0], S.mx[1], S.mx[2]};
         const bool viol = gi >= cur && gi < head && box_violates(p.x, p.y, p.z, mn, mx);
         const unsigned long long bal = __ballot(viol);
         if (!bal) break;
@@ -119,6 +136,10 @@ __device__ __forceinline__ void box_replay(BuildSh& S, const float4* __restrict_
         cur = c * WAVE + (uint32_t)f + 1u;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // lane 0's LDS writes -> the wave's next reads
         __builtin_amdgcn_wave_barrier();
+        for (int a = 0; a < 3; a++) {
+          mn[a] = S.mn[a];
+          mx[a] = S.mx[a];
+        }
         if (S.err) stop = true;
       }
     }
@@ -126,28 +147,16 @@ __device__ __forceinline__ void box_replay(BuildSh& S, const float4* __restrict_
   }
   __syncthreads();
   if (S.err || n <= PFT_REPLAY_HEAD) return;
-  // (b) the points after the head: thread-local AABB of the thread's strided points
-  float lmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, lmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (uint32_t i0 = PFT_REPLAY_HEAD + tid; i0 < n; i0 += 8u * nt) {  // eight loads in flight per round (one workgroup: latency-bound)
-    float4 q[8];
-#pragma unroll
-    for (uint32_t k = 0; k < 8u; k++) q[k] = pts[min(i0 + k * nt, n - 1u)];  // (a repeated point changes no minimum)
-#pragma unroll
-    for (uint32_t k = 0; k < 8u; k++) {
-      lmn[0] = fminf(lmn[0], q[k].x); lmx[0] = fmaxf(lmx[0], q[k].x);
-      lmn[1] = fminf(lmn[1], q[k].y); lmx[1] = fmaxf(lmx[1], q[k].y);
-      lmn[2] = fminf(lmn[2], q[k].z); lmx[2] = fmaxf(lmx[2], q[k].z);
-    }
-  }
+  // (b), second half
   for (;;) {
     const uint32_t cur = S.cur;
     const double mn[3] = {S.mn[0], S.mn[1], S.mn[2]};
     const double mx[3] = {S.mx[0], S.mx[1], S.mx[2]};
     uint32_t first = 0xffffffffu;
-    if (box_violates(lmn[0], lmn[1], lmn[2], mn, mx) || box_violates(lmx[0], lmx[1], lmx[2], mn, mx)) {
-      uint32_t i0 = PFT_REPLAY_HEAD + tid;
-      if (i0 < cur) i0 += ((cur - i0 + nt - 1) / nt) * nt;
-      for (uint32_t i = i0; i < n; i += nt) {
+    if (tid >= WAVE && (box_violates(lmn[0], lmn[1], lmn[2], mn, mx) || box_violates(lmx[0], lmx[1], lmx[2], mn, mx))) {
+      uint32_t i0 = PFT_REPLAY_HEAD + wt;
+      if (i0 < cur) i0 += ((cur - i0 + ws - 1) / ws) * ws;
+      for (uint32_t i = i0; i < n; i += ws) {
         const float4 p = pts[i];
         if (box_violates(p.x, p.y, p.z, mn, mx)) {
           first = i;
