@@ -25,6 +25,7 @@
 #define PFT_JUMP_MAX_LEVEL 4     // 2^12 cells x u16 = 8 KiB of LDS in the likelihood kernel
 #define PFT_REF_CHUNK 512        // reference points per likelihood work item
 #define PFT_BUILD_THREADS 1024
+#define PFT_LIK_GROUPS 64        // likelihood kernel: groups of workgroups that share a dynamic work-item counter
 #ifndef PFT_LIK_THREADS
 #define PFT_LIK_THREADS 1024   // likelihood workgroup size
 #endif
@@ -100,6 +101,9 @@ struct PftHeader {  // lives in HBM; written by kernels, read by later kernels (
   unsigned long long stat_queries, stat_scanned;
   unsigned long long dbg[32];    // debug-variant likelihood statistics (tools/descent_stats.py)
   unsigned long long ticks[32];  // wall_clock64() (100 MHz) at phase boundaries: [0..15] octree, [16..31] population
+  // likelihood kernel: per group of workgroups, the next work item of the group's range (one counter per 64-byte line;
+  // reset by the crop kernel of the same iteration)
+  uint32_t lik_ctr[PFT_LIK_GROUPS * 16];
 };
 
 struct PftDev {  // device pointers (host-side struct, passed by value)

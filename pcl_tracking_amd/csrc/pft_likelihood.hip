@@ -72,14 +72,27 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
                                                  uint32_t n_particles, int D, uint32_t n_crop,
                                                  const double omin[3], int abl) {
   const int lane = lane_id(), w = wave_id(), nw = blockDim.x >> 6;
-  const uint32_t gw = blockIdx.x * nw + w, tw = gridDim.x * nw;
   const uint32_t M = prm.M, nchunk = prm.nchunk;
   const uint32_t n_items = n_particles * nchunk;
+  // Work distribution.  The cost of an item depends on where its queries land, and with a static round-robin the
+  // slowest wave sets the launch time (mean wave busy 219 us, launch 250 us).  The workgroups form PFT_LIK_GROUPS
+  // groups (blockIdx % groups: spread over the XCDs); a group owns a contiguous range of items; a wave's first item is
+  // static, the following ones come from the group's counter (one atomic per item; a single counter for the whole
+  // launch serialises at one L2 line and costs 150 us).
+  const uint32_t G = min((uint32_t)PFT_LIK_GROUPS, gridDim.x), grp = blockIdx.x % G;
+  const uint32_t gq = gridDim.x / G, gr = gridDim.x % G;  // groups below gr have gq + 1 workgroups, the others gq
+  const uint32_t wgs_in_grp = gq + (grp < gr ? 1u : 0u), waves_in_grp = wgs_in_grp * (uint32_t)nw;
+  const uint32_t wgs_before = grp * gq + min(grp, gr);
+  // the group's share of the items is proportional to its workgroups
+  const uint32_t it_begin = (uint32_t)((unsigned long long)n_items * wgs_before / gridDim.x);
+  const uint32_t it_end = (uint32_t)((unsigned long long)n_items * (wgs_before + wgs_in_grp) / gridDim.x);
+  const uint32_t lw = (blockIdx.x / G) * (uint32_t)nw + (uint32_t)w;
+  uint32_t* ctr = &d.hdr->lik_ctr[grp * 16u];
   const double res = prm.res;
   const double maxd2 = prm.maxd2;
   const double wd = prm.dist_w, whsv = prm.hsv_w;
   const float hw = prm.h_w, sw = prm.s_w, vw = prm.v_w;
-  for (uint32_t item_v = gw; item_v < n_items; item_v += tw) {
+  for (uint32_t item_v = it_begin + lw; item_v < it_end;) {
     // the work item is wave-uniform: said explicitly, so the particle's matrix is fetched with scalar loads and
     // lives in SGPRs
     const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item_v);
@@ -291,6 +304,11 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
     }
     val = wave_sum(val);
     if (lane == 0) d.partial[(size_t)pi * nchunk + ch] = val;
+    {
+      uint32_t nx = 0;
+      if (lane == 0) nx = it_begin + waves_in_grp + atomicAdd(ctr, 1u);
+      item_v = (uint32_t)__shfl((int)nx, 0);
+    }
     if (DEBUG_NN) {
       st_q = wave_sum(st_q);
       st_s = wave_sum(st_s);
