@@ -74,6 +74,7 @@ struct pft_tracker {
   uint32_t dbg_builds = 0;
   uint32_t Pcap = 0;  // particle capacity of the buffers (== P_total unless KLD-adaptive)
   uint32_t* d_alias_pos = nullptr;
+  float* d_raw_w = nullptr;
   PftHeader* d_hdr = nullptr;
   int32_t* d_nn_idx = nullptr;
   float* d_nn_d2 = nullptr;
@@ -329,6 +330,7 @@ static void sync_dev(pft_tracker* t) {
   d.kld_table = t->d_kld_table;
   d.kld_bins = t->d_kld_bins;
   d.alias_pos = t->d_alias_pos;
+  d.raw_w = t->d_raw_w;
   d.hdr = t->d_hdr;
   d.nn_idx = t->d_nn_idx;
   d.nn_d2 = t->d_nn_d2;
@@ -453,6 +455,7 @@ extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
   A(dalloc(&t->d_alias_pref, 2 * Pt));
   A(dalloc(&t->d_pop_part, (size_t)PFT_POPM_MAX_WGS * 16));
   A(dalloc(&t->d_alias_pos, Pt));
+  A(dalloc(&t->d_raw_w, Pt));
   if (cfg->exact_nearest) {
     A(dalloc(&t->d_eg_start, (size_t)PFT_EG_CAP + 1));
     A(dalloc(&t->d_eg_cnt, (size_t)PFT_EG_CAP));
@@ -512,7 +515,7 @@ extern "C" void pft_destroy(pft_tracker* t) {
   dfree(t->d_leaf_pts); dfree(t->d_leaf_order); dfree(t->d_pt_node); dfree(t->d_pt_key); dfree(t->d_pt_tmp);
   dfree(t->d_pt_key64); dfree(t->sort.keys[0]); dfree(t->sort.keys[1]); dfree(t->sort.vals[0]); dfree(t->sort.vals[1]);
   dfree(t->sort.hist); dfree(t->sort.tile_cnt); dfree(t->sort.tile_box); if (t->h_stat) hipHostFree(t->h_stat);
-  dfree(t->d_partial); dfree(t->d_alias_list); dfree(t->d_alias_pos);
+  dfree(t->d_partial); dfree(t->d_alias_list); dfree(t->d_alias_pos); dfree(t->d_raw_w);
   dfree(t->d_alias_pref); dfree(t->d_pop_part); dfree(t->d_kld_table); dfree(t->d_kld_bins); dfree(t->d_eg_start); dfree(t->d_eg_cnt); dfree(t->d_eg_tile); dfree(t->d_ec_slot); dfree(t->d_ec_cells); dfree(t->d_ec_count); dfree(t->d_ec_base); dfree(t->d_ec_list); dfree(t->d_hdr); dfree(t->d_nn_idx); dfree(t->d_nn_d2); dfree(t->d_dbg_part);
   dfree(t->d_dbg_hdr); dfree(t->d_dbg_f);
   if (t->own_stream && t->stream) hipStreamDestroy(t->stream);
@@ -745,7 +748,10 @@ extern "C" int pft_compute(pft_tracker* t) {
       ProfScope ps(t, PFT_K_POPULATION);
       // raw weights from the partial sums, then weight()'s normalizeWeight(); use_change_detector_ == false
       // => changed_ = true => update(); the alias prefix form feeds the next resample
-      pftk_population(t->stream, t->prm, t->dev, t->prm.kld ? t->Pcap : t->prm.P_total, 1, 1, 1, 1);
+      // (the sums of the partial sums are taken by a many-workgroup kernel first: the population stage is one
+      // workgroup, and reading P x nchunk doubles through one CU costs more than a launch)
+      pftk_finalize_raw(t->stream, t->prm, t->dev, t->prm.kld ? t->Pcap : t->prm.P_total, t->d_raw_w);
+      pftk_population(t->stream, t->prm, t->dev, t->prm.kld ? t->Pcap : t->prm.P_total, 2, 1, 1, 1);
     }
     t->changed = true;
   }

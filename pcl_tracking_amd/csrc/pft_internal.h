@@ -23,7 +23,7 @@
 #define PFT_TABLE_MAX_DEPTH 10
 #define PFT_MAX_GROW 40
 #define PFT_JUMP_MAX_LEVEL 4     // 2^12 cells x u16 = 8 KiB of LDS in the likelihood kernel
-#define PFT_REF_CHUNK 512        // reference points per likelihood work item
+#define PFT_REF_CHUNK 256        // reference points per likelihood work item
 #define PFT_BUILD_THREADS 1024
 #define PFT_LIK_GROUPS 64        // likelihood kernel: groups of workgroups that share a dynamic work-item counter
 #ifndef PFT_LIK_THREADS
@@ -135,6 +135,7 @@ struct PftDev {  // device pointers (host-side struct, passed by value)
   int32_t* alias_list;   // [0,P): small list, [P,2P): large list
   double* alias_pref;    // [0,P): running deficit, [P,2P): running excess
   uint32_t* alias_pos;   // [P]
+  float* raw_w;          // [P_local] raw likelihood weights, w = -(float) sum of the particle's partial sums (k_finalize_raw)
   double* pop_part;      // [PFT_POPM_MAX_WGS][16] per-workgroup partials of the many-workgroup population path
   PftHeader* hdr;
   const uint32_t* p_active;  // KLD variant: &hdr->p_active (kernels take the particle count from here), else null

@@ -273,8 +273,10 @@ __global__ __launch_bounds__(1024) void k_crop_scatter(const float4* __restrict_
 
 // raw weight of a particle: w = -(float) val  (ApproxNearestPairPointCloudCoherence::computeCoherence)
 __global__ void k_finalize_raw(const double* __restrict__ partial, uint32_t nchunk, uint32_t n,
-                               pft_particle* __restrict__ part, float* __restrict__ raw_out) {
+                               pft_particle* __restrict__ part, float* __restrict__ raw_out,
+                               const uint32_t* __restrict__ p_active) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p_active) n = *p_active;  // KLD variant: particle_num_ lives on the device
   if (i >= n) return;
   double v = 0.0;
   for (uint32_t c = 0; c < nchunk; c++) v += partial[(size_t)i * nchunk + c];
@@ -372,5 +374,5 @@ void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d, bool from_par
 void pftk_finalize_raw(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, float* raw_out) {
   if (!n_particles) return;
   hipLaunchKernelGGL(k_finalize_raw, dim3(cdiv(n_particles, 256)), dim3(256), 0, s, d.partial, p.nchunk, n_particles,
-                     d.part_cur, raw_out);
+                     d.part_cur, raw_out, d.p_active);
 }

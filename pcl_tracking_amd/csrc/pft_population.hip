@@ -37,7 +37,9 @@ __device__ __forceinline__ void population_body(const PftParams& prm, const PftD
     const uint32_t i = tid + j * NT;
     wr[j] = 0.0f;
     if (i < n) {
-      if (from_partials) {  // w = -(float) val, val = sum of the per-chunk likelihood partial sums
+      if (from_partials == 2) {  // raw weights already summed by k_finalize_raw
+        wr[j] = d.raw_w[i];
+      } else if (from_partials) {  // w = -(float) val, val = sum of the per-chunk likelihood partial sums
         double v = 0.0;
         for (uint32_t c = 0; c < prm.nchunk; c++) v += d.partial[(size_t)i * prm.nchunk + c];
         wr[j] = -(float)v;
@@ -291,7 +293,10 @@ __global__ __launch_bounds__(PFT_POPM_THREADS) void k_popm_minmax(PftParams prm,
     if (r >= n) break;
     const uint32_t i = n - 1 - r;
     float wf;
-    if (from_partials) {
+    if (from_partials == 2) {
+      wf = d.raw_w[i];
+      P[i].weight = wf;
+    } else if (from_partials) {
       double v = 0.0;
       for (uint32_t c = 0; c < prm.nchunk; c++) v += d.partial[(size_t)i * prm.nchunk + c];
       wf = -(float)v;
