@@ -412,9 +412,16 @@ __global__ __launch_bounds__(256) void k_likelihood_exact(PftParams prm, PftDev 
   const float hw = prm.h_w, sw = prm.s_w, vw = prm.v_w;
   const uint32_t M = prm.M, nchunk = prm.nchunk;
   const int lane = lane_id(), nw = blockDim.x >> 6;
-  const uint32_t gw = blockIdx.x * nw + wave_id(), tw = gridDim.x * nw;
   const uint32_t n_items = n_particles * nchunk;
-  for (uint32_t item_v = gw; item_v < n_items; item_v += tw) {
+  // work items handed out dynamically inside groups of workgroups, as in pft_likelihood.hip (list lengths vary a lot)
+  const uint32_t G = min((uint32_t)PFT_LIK_GROUPS, gridDim.x), grp = blockIdx.x % G;
+  const uint32_t gq = gridDim.x / G, gr = gridDim.x % G;
+  const uint32_t wgs_in_grp = gq + (grp < gr ? 1u : 0u), waves_in_grp = wgs_in_grp * (uint32_t)nw;
+  const uint32_t wgs_before = grp * gq + min(grp, gr);
+  const uint32_t it_begin = (uint32_t)((unsigned long long)n_items * wgs_before / gridDim.x);
+  const uint32_t it_end = (uint32_t)((unsigned long long)n_items * (wgs_before + wgs_in_grp) / gridDim.x);
+  uint32_t* ctr = &d.hdr->lik_ctr[grp * 16u];
+  for (uint32_t item_v = it_begin + (blockIdx.x / G) * (uint32_t)nw + wave_id(); item_v < it_end;) {
     const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item_v);
     const uint32_t pi = item / nchunk, ch = item % nchunk;
     float T[12];
@@ -526,6 +533,9 @@ __global__ __launch_bounds__(256) void k_likelihood_exact(PftParams prm, PftDev 
     }
     val = wave_sum(val);
     if (lane == 0) d.partial[(size_t)pi * nchunk + ch] = val;
+    uint32_t nx = 0;
+    if (lane == 0) nx = it_begin + waves_in_grp + atomicAdd(ctr, 1u);
+    item_v = (uint32_t)__shfl((int)nx, 0);
   }
 }
 
