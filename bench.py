@@ -302,14 +302,16 @@ def main():
             # interpretation aid (SURVEY 8d "secondary (VALU) roof"): the kernel's working set is LDS/L2-resident and it
             # is VALU-issue bound.  Instruction count per launch from the committed PMC pass of this very workload
             # (profiles/r01_pmc_sq_counters.txt: SQ_INSTS_VALU of k_likelihood<false>); the duration is the live one.
-            valu_insts = 1.554e8
-            # nominal issue rate: one wave64 VALU instruction per 4 cycles per SIMD, 1024 SIMDs at 2.4 GHz.  Measured
-            # on this part (tools/micro/valu_rate_test.hip): compares, selects, shifts, bit-field and 3-operand
-            # instructions take 4.1-4.4 cycles, plain add/sub/mul/and/or 2.5-2.7 -- about a third of this kernel's mix.
-            valu_peak = 256 * 4 * 2.4e9 / 4.0
+            valu_insts = 1.572e8
+            # Measured on this part (tools/micro/valu_rate_test.hip): a wave64 VALU instruction occupies its SIMD for
+            # 2.5-2.7 cycles if it is a plain add / sub / mul / and / or, 4.1-4.4 cycles otherwise (compares, selects,
+            # shifts, bit-field, fused and three-operand forms: two thirds of this kernel's child selection).  The
+            # figure below is the SIMD time the launch spends per instruction: between those two costs = the VALU
+            # pipes are busy for essentially the whole launch.
             out["roofline"]["valu_issue"] = {
                 "wave_insts_per_launch": valu_insts, "wave_insts_per_s": valu_insts / lik_avg_s,
-                "nominal_peak_wave_insts_per_s": valu_peak, "frac_of_nominal": valu_insts / lik_avg_s / valu_peak,
+                "simd_cycles_per_wave_inst": lik_avg_s * 2.4e9 * 256 * 4 / valu_insts,
+                "measured_cost_cycles": {"add_sub_mul_and_or": 2.5, "compare_select_shift_bitfield_fma": 4.2},
                 "source": "profiles/r01_pmc_sq_counters.txt (SQ_INSTS_VALU of this workload); duration measured live"}
         if world == 1 and not ARGS.no_cpu_baseline:
             cores = os.cpu_count() or 1
