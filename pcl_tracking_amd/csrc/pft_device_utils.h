@@ -206,6 +206,11 @@ struct AliasView {
   const double* E;    // inclusive running excess over H
   const uint32_t* pos;  // per particle: position in its list | large << 31
   uint32_t m, nh, n;
+  // optional coarse levels of D and E (every sD-th / sE-th element, in LDS): a search then needs log2(s) dependent
+  // global loads instead of log2(n)
+  const double* cD = nullptr;
+  const double* cE = nullptr;
+  uint32_t sD = 0, sE = 0;
 };
 
 __device__ __forceinline__ uint32_t lower_bound_ge(const double* a, uint32_t n, double x) {
@@ -225,6 +230,40 @@ __device__ __forceinline__ uint32_t upper_bound_gt(const double* a, uint32_t n, 
   return lo;
 }
 
+// the same searches through a coarse level c[j] = a[min((j + 1) * s, n) - 1] (the arrays are non-decreasing)
+__device__ __forceinline__ uint32_t lower_bound_ge2(const double* a, uint32_t n, double x, const double* c, uint32_t s) {
+  if (!c || n == 0) return lower_bound_ge(a, n, x);
+  uint32_t lo = 0, hi = (n + s - 1) / s;
+  const uint32_t nb = hi;
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (c[mid] >= x) hi = mid; else lo = mid + 1;
+  }
+  if (lo == nb) return n;
+  uint32_t b = lo * s, e = min(n, b + s);
+  while (b < e) {
+    uint32_t mid = (b + e) >> 1;
+    if (a[mid] >= x) e = mid; else b = mid + 1;
+  }
+  return b;
+}
+__device__ __forceinline__ uint32_t upper_bound_gt2(const double* a, uint32_t n, double x, const double* c, uint32_t s) {
+  if (!c || n == 0) return upper_bound_gt(a, n, x);
+  uint32_t lo = 0, hi = (n + s - 1) / s;
+  const uint32_t nb = hi;
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (c[mid] > x) hi = mid; else lo = mid + 1;
+  }
+  if (lo == nb) return n;
+  uint32_t b = lo * s, e = min(n, b + s);
+  while (b < e) {
+    uint32_t mid = (b + e) >> 1;
+    if (a[mid] > x) e = mid; else b = mid + 1;
+  }
+  return b;
+}
+
 // q[k] of the table; *flipped_next receives the alias of a large that dropped below 1 (or -1)
 __device__ __forceinline__ double alias_q(const AliasView& v, uint32_t k, float wk, int32_t* alias_if_large) {
   double q0 = (double)(wk * (float)v.n);  // float product widened to double, as genAliasTable does
@@ -233,7 +272,7 @@ __device__ __forceinline__ double alias_q(const AliasView& v, uint32_t k, float 
   if (!(pp >> 31) || v.m == 0) return q0;  // smalls keep their q; without smalls nothing is paired
   const uint32_t pos = pp & 0x7fffffffu;
   const double Ek = v.E[pos];
-  const uint32_t is = upper_bound_gt(v.D, v.m, Ek);
+  const uint32_t is = upper_bound_gt2(v.D, v.m, Ek, v.cD, v.sD);
   if (is < v.m) {  // dropped below 1 while absorbing l_is: becomes a small, paired with the next large
     if (pos + 1 < v.nh) *alias_if_large = v.H[pos + 1];
     return 1.0 + Ek - v.D[is];
@@ -249,6 +288,6 @@ __device__ __forceinline__ int32_t alias_a_small(const AliasView& v, uint32_t k)
   if (v.nh == 0) return (int32_t)k;
   const uint32_t pos = v.pos[k] & 0x7fffffffu;
   const double dprev = pos > 0 ? v.D[pos - 1] : 0.0;
-  const uint32_t kk = lower_bound_ge(v.E, v.nh, dprev);
+  const uint32_t kk = lower_bound_ge2(v.E, v.nh, dprev, v.cE, v.sE);
   return kk < v.nh ? v.H[kk] : (int32_t)k;
 }

@@ -58,6 +58,21 @@ __global__ void k_resample(PftParams p, const pft_particle* __restrict__ old, Al
                            const PftHeader* __restrict__ hdr, uint32_t epoch, pft_particle* __restrict__ out,
                            float* __restrict__ mats) {
   uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ double cD[256], cE[256];
+  if (!TABLE) {  // coarse levels of the two prefix arrays: 8 of the 13 dependent loads of a search become LDS reads
+    v.m = hdr->alias_m;
+    v.nh = hdr->alias_nh;
+    v.sD = (v.m + 255u) / 256u;
+    v.sE = (v.nh + 255u) / 256u;
+    const uint32_t t = threadIdx.x;
+    if (t < 256u) {
+      if (v.m && t * v.sD < v.m) cD[t] = v.D[min((t + 1u) * v.sD, v.m) - 1u];
+      if (v.nh && t * v.sE < v.nh) cE[t] = v.E[min((t + 1u) * v.sE, v.nh) - 1u];
+    }
+    __syncthreads();
+    v.cD = cD;
+    v.cE = cE;
+  }
   if (li >= p.P_local) return;
   uint32_t g = p.id_offset + li;
   pft_particle s;
@@ -73,8 +88,6 @@ __global__ void k_resample(PftParams p, const pft_particle* __restrict__ old, Al
     if (TABLE) {
       target = (rU < tq[k]) ? k : ta[k];
     } else {
-      v.m = hdr->alias_m;
-      v.nh = hdr->alias_nh;
       int32_t a_large;
       const double qk = alias_q(v, (uint32_t)k, old[k].weight, &a_large);
       if (rU < qk)
