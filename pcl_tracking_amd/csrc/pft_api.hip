@@ -49,6 +49,7 @@ struct pft_tracker {
   float* d_bbox_part = nullptr;
   float* d_bbox6 = nullptr;
   uint32_t* d_crop_counts = nullptr;
+  unsigned long long* d_crop_slots = nullptr;
   float4* d_crop_pts = nullptr;
   int32_t* d_crop_idx = nullptr;
   uint32_t* d_words = nullptr;
@@ -299,6 +300,7 @@ static void sync_dev(pft_tracker* t) {
   d.bbox_grid = (uint32_t)t->num_cus;
   d.bbox6 = t->bound_bbox6 ? static_cast<float*>(t->bound_bbox6) : t->d_bbox6;
   d.crop_counts = t->d_crop_counts;
+  d.crop_slots = t->d_crop_slots;
   d.crop_pts = t->d_crop_pts;
   d.crop_idx = t->d_crop_idx;
   d.words = t->d_words;
@@ -343,7 +345,7 @@ static int ensure_input_capacity(pft_tracker* t, uint32_t n) {
     return PFT_ERR_CAPACITY;
   }
   hipStreamSynchronize(t->stream);
-  dfree(t->d_in_raw); dfree(t->d_in_pts); dfree(t->d_crop_counts); dfree(t->d_crop_pts); dfree(t->d_crop_idx);
+  dfree(t->d_in_raw); dfree(t->d_in_pts); dfree(t->d_crop_counts); dfree(t->d_crop_slots); dfree(t->d_crop_pts); dfree(t->d_crop_idx);
   dfree(t->d_words); dfree(t->d_leaf_pts); dfree(t->d_leaf_order); dfree(t->d_pt_node); dfree(t->d_pt_key);
   dfree(t->d_pt_tmp); dfree(t->d_pt_key64);
   dfree(t->sort.keys[0]); dfree(t->sort.keys[1]); dfree(t->sort.vals[0]); dfree(t->sort.vals[1]);
@@ -353,6 +355,8 @@ static int ensure_input_capacity(pft_tracker* t, uint32_t n) {
   HIPCHK(t, dalloc(&t->d_in_raw, cap));
   HIPCHK(t, dalloc(&t->d_in_pts, cap));
   HIPCHK(t, dalloc(&t->d_crop_counts, (size_t)(cap / 1024 + 2)));
+  HIPCHK(t, dalloc(&t->d_crop_slots, (size_t)(cap / 1024 + 2)));
+  HIPCHK(t, hipMemsetAsync(t->d_crop_slots, 0, (size_t)(cap / 1024 + 2) * sizeof(unsigned long long), t->stream));
   HIPCHK(t, dalloc(&t->d_crop_pts, cap));
   HIPCHK(t, dalloc(&t->d_crop_idx, cap));
   HIPCHK(t, dalloc(&t->d_words, t->max_words));
@@ -511,7 +515,7 @@ extern "C" void pft_destroy(pft_tracker* t) {
   dfree(t->d_ref_raw); dfree(t->d_ref_xyz); dfree(t->d_ref_hsv);
   dfree(t->d_in_raw); dfree(t->d_in_pts);
   dfree(t->d_part[0]); dfree(t->d_part[1]); dfree(t->d_mats); dfree(t->d_bbox_part); dfree(t->d_bbox6);
-  dfree(t->d_crop_counts); dfree(t->d_crop_pts); dfree(t->d_crop_idx); dfree(t->d_words); dfree(t->d_centers); dfree(t->d_jump); dfree(t->d_ref_perm);
+  dfree(t->d_crop_counts); dfree(t->d_crop_slots); dfree(t->d_crop_pts); dfree(t->d_crop_idx); dfree(t->d_words); dfree(t->d_centers); dfree(t->d_jump); dfree(t->d_ref_perm);
   dfree(t->d_leaf_pts); dfree(t->d_leaf_order); dfree(t->d_pt_node); dfree(t->d_pt_key); dfree(t->d_pt_tmp);
   dfree(t->d_pt_key64); dfree(t->sort.keys[0]); dfree(t->sort.keys[1]); dfree(t->sort.vals[0]); dfree(t->sort.vals[1]);
   dfree(t->sort.hist); dfree(t->sort.tile_cnt); dfree(t->sort.tile_box); if (t->h_stat) hipHostFree(t->h_stat);

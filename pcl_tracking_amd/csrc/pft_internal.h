@@ -104,6 +104,7 @@ struct PftHeader {  // lives in HBM; written by kernels, read by later kernels (
   // likelihood kernel: per group of workgroups, the next work item of the group's range (one counter per 64-byte line;
   // reset by the crop kernel of the same iteration)
   uint32_t lik_ctr[PFT_LIK_GROUPS * 16];
+  uint32_t crop_ticket;  // one-pass crop: workgroups take their logical index here (the last one resets it)
 };
 
 struct PftDev {  // device pointers (host-side struct, passed by value)
@@ -118,6 +119,7 @@ struct PftDev {  // device pointers (host-side struct, passed by value)
   uint32_t bbox_grid;
   float* bbox6;             // {-xmin,-ymin,-zmin,xmax,ymax,zmax}: max-reducible across ranks
   uint32_t* crop_counts;
+  unsigned long long* crop_slots;  // one-pass crop: per workgroup (launch epoch << 32) | kept points, published with atomics
   float4* crop_pts;
   int32_t* crop_idx;
   uint32_t* words;

@@ -284,6 +284,77 @@ __global__ __launch_bounds__(1024) void k_crop_scatter(const float4* __restrict_
   }
 }
 
+// The same compaction in ONE launch.  A workgroup takes its logical index from a ticket (so every workgroup with a lower
+// index is already running: waiting for them cannot deadlock, whatever the dispatch order), counts its kept points,
+// publishes (launch epoch << 32 | count) with an atomic, and one wave collects the counts of its predecessors with
+// atomic loads, spinning on the few that are not there yet (bounded: a failure raises the error flag instead of
+// hanging).  50 000 points are 49 workgroups, so the chain is one step deep in practice.
+template <bool FROM_PART>
+__global__ __launch_bounds__(1024) void k_crop_onepass(const float4* __restrict__ in, uint32_t N,
+                                                       const float* __restrict__ bbox6, const float* __restrict__ part,
+                                                       uint32_t nparts, unsigned long long* __restrict__ slots,
+                                                       uint32_t epoch, int argorder, float4* __restrict__ out,
+                                                       int32_t* __restrict__ out_idx, PftHeader* __restrict__ hdr,
+                                                       uint32_t* host_stat) {
+  __shared__ uint32_t s_scan[20];
+  __shared__ uint32_t s_base, s_b;
+  __shared__ float s6[6];
+  if (threadIdx.x == 0) s_b = atomicAdd(&hdr->crop_ticket, 1u);
+  if (FROM_PART) {
+    reduce_partials(part, nparts, s6);
+  } else if (threadIdx.x < 6) {
+    s6[threadIdx.x] = bbox6[threadIdx.x];
+  }
+  __syncthreads();
+  const uint32_t b = s_b, nb = gridDim.x;
+  const uint32_t i = b * blockDim.x + threadIdx.x;
+  bool keep = false;
+  float4 p = make_float4(0, 0, 0, 0);
+  if (i < N) {
+    p = in[i];
+    keep = crop_keep(p, s6);
+  }
+  uint32_t total;
+  const uint32_t pos = block_excl_scan<uint32_t>(keep ? 1u : 0u, s_scan, &total);
+  if (threadIdx.x == 0) atomicExch(&slots[b], ((unsigned long long)epoch << 32) | total);
+  if (wave_id() == 7) {
+    uint32_t t = 0;
+    bool failed = false;
+    for (uint32_t q = lane_id(); q < b; q += WAVE) {
+      unsigned long long v = 0;
+      uint32_t spins = 0;
+      for (;;) {
+        v = __hip_atomic_load(&slots[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(v >> 32) == epoch) break;
+        if (++spins > (1u << 24)) {
+          failed = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      t += (uint32_t)v;
+    }
+    t = wave_sum(t);
+    if (__ballot(failed) && lane_id() == 0) hdr->error |= 4u;
+    if (lane_id() == 0) s_base = t;
+  }
+  __syncthreads();
+  if (keep) {
+    uint32_t kk = hsv_pack_of_rgba(__float_as_uint(p.w), argorder);
+    out[s_base + pos] = make_float4(p.x, p.y, p.z, __uint_as_float(kk));
+    out_idx[s_base + pos] = (int32_t)i;
+  }
+  if (b == nb - 1 && threadIdx.x < PFT_LIK_GROUPS) hdr->lik_ctr[threadIdx.x * 16u] = 0u;
+  if (b == nb - 1 && threadIdx.x == 0) {
+    atomicExch(&hdr->crop_ticket, 0u);  // every workgroup of this launch has taken its ticket by now
+    hdr->n_crop = s_base + total;
+    if (host_stat) host_stat[0] = s_base + total;
+    hdr->bbox[0] = -s6[0]; hdr->bbox[1] = s6[3];
+    hdr->bbox[2] = -s6[1]; hdr->bbox[3] = s6[4];
+    hdr->bbox[4] = -s6[2]; hdr->bbox[5] = s6[5];
+  }
+}
+
 // raw weight of a particle: w = -(float) val  (ApproxNearestPairPointCloudCoherence::computeCoherence)
 __global__ void k_finalize_raw(const double* __restrict__ partial, uint32_t nchunk, uint32_t n,
                                pft_particle* __restrict__ part, float* __restrict__ raw_out,
@@ -372,6 +443,19 @@ void pftk_aabb(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_pa
 }
 void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d, bool from_part) {
   uint32_t nb = cdiv(d.N ? d.N : 1, 1024);
+  static const bool two_pass = getenv("PFT_CROP_TWO_PASS") != nullptr;  // A/B timing and cross-check
+  if (!two_pass) {
+    static uint32_t epoch = 0;  // (shared by all handles: only has to differ from launch to launch on one stream)
+    epoch++;
+    if (epoch == 0) epoch = 1;  // 0 is what freshly allocated slots hold
+    if (from_part)
+      hipLaunchKernelGGL(k_crop_onepass<true>, dim3(nb), dim3(1024), 0, s, d.in_pts, d.N, d.bbox6, d.bbox_part, d.bbox_grid,
+                         d.crop_slots, epoch, p.hsv_argorder, d.crop_pts, d.crop_idx, d.hdr, d.host_stat);
+    else
+      hipLaunchKernelGGL(k_crop_onepass<false>, dim3(nb), dim3(1024), 0, s, d.in_pts, d.N, d.bbox6, d.bbox_part, d.bbox_grid,
+                         d.crop_slots, epoch, p.hsv_argorder, d.crop_pts, d.crop_idx, d.hdr, d.host_stat);
+    return;
+  }
   if (from_part) {
     hipLaunchKernelGGL(k_crop_count<true>, dim3(nb), dim3(1024), 0, s, d.in_pts, d.N, d.bbox6, d.bbox_part,
                        d.bbox_grid, d.crop_counts);

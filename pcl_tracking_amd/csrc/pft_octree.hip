@@ -542,7 +542,7 @@ __global__ __launch_bounds__(PFT_BUILD_THREADS) void k_octree_build(PftParams pr
 
   STAMP(0);
   if (tid == 0) {
-    S.err = 0;
+    S.err = hdr->error & 4u;  // (bit 2: the one-pass crop gave up waiting for a predecessor: sticky)
     S.ngrow = 0;
     S.depth = 0;
     S.cur = 1;

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(1024) void k_so_replay(PftParams prm, PftDev d, con
   const float4* pts = d.crop_pts;
   const double res = prm.res;
   if (tid == 0) {
-    S.err = 0;
+    S.err = hdr->error & 4u;  // (bit 2: the one-pass crop gave up waiting for a predecessor: sticky)
     S.ngrow = 0;
     S.depth = 0;
     S.cur = 1;
