@@ -443,7 +443,7 @@ void pftk_aabb(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_pa
 }
 void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d, bool from_part) {
   uint32_t nb = cdiv(d.N ? d.N : 1, 1024);
-  static const bool two_pass = getenv("PFT_CROP_TWO_PASS") != nullptr;  // A/B timing and cross-check
+  const bool two_pass = getenv("PFT_CROP_TWO_PASS") != nullptr;  // A/B timing and cross-check (read per call: tests toggle it)
   if (!two_pass) {
     static uint32_t epoch = 0;  // (shared by all handles: only has to differ from launch to launch on one stream)
     epoch++;

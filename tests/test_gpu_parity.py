@@ -441,6 +441,25 @@ def test_compute_other_iteration_counts(gpu, orc, data, iters):
             assert abs(float(rg[k]) - float(ro[k])) < 1e-4, (f, k)
 
 
+def test_crop_one_pass_and_two_pass_agree(gpu, orc, data, monkeypatch):
+    """the order-preserving crop in one launch (ticketed workgroups) against the count + scatter pair and the oracle"""
+    p = particles_around(data["gt"], 96, 17, sig_t=0.2, sig_r=0.5)  # a wide box: the crop keeps most of the cloud
+    res = []
+    for two in (False, True):
+        if two:
+            monkeypatch.setenv("PFT_CROP_TWO_PASS", "1")
+        g, o = make_pair(gpu, orc, data["model"], data["scene"], 96)
+        G = g.evalWeights(p, want_nn=True)
+        res.append(G)
+        if not two:
+            O = o.eval_weights(p, want_nn=True, mats=g.debugPoseToMatrix(p))
+            np.testing.assert_array_equal(G["crop_idx"], O["crop_idx"])
+            assert len(G["crop_idx"]) > 5000
+    np.testing.assert_array_equal(res[0]["crop_idx"], res[1]["crop_idx"])
+    np.testing.assert_array_equal(res[0]["nn_idx"], res[1]["nn_idx"])
+    np.testing.assert_array_equal(res[0]["raw"], res[1]["raw"])
+
+
 # ---- SURVEY 8f row 4: NearestPairPointCloudCoherence (true nearest neighbour) -----------------------------------
 @pytest.mark.parametrize("M,N,P,maxd,shells", [(256, 6000, 48, 0.1, False), (513, 20000, 33, 0.1, False), (64, 900, 20, 0.03, False),
                                                (300, 50000, 16, 0.25, False), (256, 6000, 48, 0.1, True), (300, 50000, 16, 0.25, True)])
