@@ -436,6 +436,7 @@ extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
   p.id_offset = p.P_local * (uint32_t)cfg->rank;
   p.M = 0;
   p.nchunk = 1;
+  p.ref_chunk = PFT_REF_CHUNK;
   p.kld = cfg->kld_adaptive ? 1u : 0u;
   p.kld_max = (uint32_t)cfg->maximum_particle_num;
   p.kld_z = pft_kld_normal_quantile(cfg->kld_delta);
@@ -548,7 +549,19 @@ extern "C" int pft_set_reference(pft_tracker* t, const pft_point_xyzrgba* pts, s
     t->ref_cap = (uint32_t)n;
   }
   t->prm.M = (uint32_t)n;
-  t->prm.nchunk = (uint32_t)((n + PFT_REF_CHUNK - 1) / PFT_REF_CHUNK);
+  {
+    // Work item of the likelihood kernels = (particle, ref_chunk reference points).  256 points amortise the per-item
+    // cost best when there are plenty of items; with few particles (the reference's own 400-500) smaller items keep
+    // all CUs busy: aim at two items per resident wave.
+    const uint64_t pl = t->prm.kld ? t->Pcap : t->prm.P_local;
+    const uint64_t want_items = 2ull * (uint64_t)PFT_LIK_WGS_PER_CU * (uint64_t)t->num_cus * (PFT_LIK_THREADS / 64u);
+    uint64_t c = pl * (uint64_t)n / (want_items ? want_items : 1);
+    c = (c / 64u) * 64u;
+    if (c < 64u) c = 64u;
+    if (c > PFT_REF_CHUNK) c = PFT_REF_CHUNK;
+    t->prm.ref_chunk = (uint32_t)c;
+  }
+  t->prm.nchunk = (uint32_t)((n + t->prm.ref_chunk - 1) / t->prm.ref_chunk);
   if (t->prm.nchunk == 0) t->prm.nchunk = 1;
   dfree(t->d_partial);
   HIPCHK(t, dalloc(&t->d_partial, (size_t)(t->prm.kld ? t->Pcap : t->prm.P_local) * t->prm.nchunk));

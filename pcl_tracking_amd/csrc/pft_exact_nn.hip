@@ -427,8 +427,8 @@ __global__ __launch_bounds__(256) void k_likelihood_exact(PftParams prm, PftDev 
     float T[12];
     load_matrix(d.mats, pi, T);
     double val = 0.0;
-    const uint32_t jend = min(M, (ch + 1) * (uint32_t)PFT_REF_CHUNK);
-    for (uint32_t j = ch * PFT_REF_CHUNK + lane; j < jend; j += WAVE) {
+    const uint32_t jend = min(M, (ch + 1) * prm.ref_chunk);
+    for (uint32_t j = ch * prm.ref_chunk + lane; j < jend; j += WAVE) {
       const float4 r = d.ref_xyz[j];
       float qx, qy, qz;
       xform(T, r.x, r.y, r.z, qx, qy, qz);

@@ -23,7 +23,7 @@
 #define PFT_TABLE_MAX_DEPTH 10
 #define PFT_MAX_GROW 40
 #define PFT_JUMP_MAX_LEVEL 4     // 2^12 cells x u16 = 8 KiB of LDS in the likelihood kernel
-#define PFT_REF_CHUNK 256        // reference points per likelihood work item
+#define PFT_REF_CHUNK 256        // reference points per likelihood work item (upper limit; PftParams::ref_chunk)
 #define PFT_BUILD_THREADS 1024
 #define PFT_LIK_GROUPS 64        // likelihood kernel: groups of workgroups that share a dynamic work-item counter
 #ifndef PFT_LIK_THREADS
@@ -54,6 +54,7 @@ struct PftParams {  // immutable per handle, passed by value to kernels
   uint32_t seed_lo, seed_hi;
   uint32_t P_total, P_local, id_offset;
   uint32_t M, nchunk;
+  uint32_t ref_chunk;  // reference points per likelihood work item: 64 .. PFT_REF_CHUNK, smaller when there are few particles
   // KLD-adaptive variant (KLDAdaptiveParticleFilterOMPTracker, auto_tracking.cpp:207-222)
   uint32_t kld;          // 1: the particle count changes at every resample and lives in PftHeader::p_active
   uint32_t kld_max;      // maximum_particle_number_

@@ -101,8 +101,8 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
     load_matrix(d.mats, pi, T);
     double val = 0.0;
     unsigned long long st_q = 0, st_s = 0;
-    const uint32_t jend = min(M, (ch + 1) * (uint32_t)PFT_REF_CHUNK);
-    const uint32_t j0 = ch * PFT_REF_CHUNK + lane;
+    const uint32_t jend = min(M, (ch + 1) * prm.ref_chunk);
+    const uint32_t j0 = ch * prm.ref_chunk + lane;
     float4 rnext = j0 < jend ? d.ref_xyz[j0] : make_float4(0, 0, 0, 0);
     for (uint32_t j = j0; j < jend; j += WAVE) {
       const float4 r = rnext;
