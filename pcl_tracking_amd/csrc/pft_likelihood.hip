@@ -251,10 +251,22 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         d.nn_d2[o] = bd;
         st_q += 1;
         st_s += le - ls;
-        // distribution of the descent work: per query and per wave (max over lanes)
-        atomicAdd(&d.hdr->dbg[dbg_gen < 10 ? dbg_gen : 10], 1ull);
-        atomicAdd(&d.hdr->dbg[11], (unsigned long long)dbg_jump);
-        atomicAdd(&d.hdr->dbg[27 + (dbg_hard < 4 ? dbg_hard : 4)], 1ull);
+        // distribution of the descent work: per query (counted per wave with ballots: one atomic per bucket and wave,
+        // not per query) and per wave (max over lanes)
+        {
+          const int first = __ffsll((long long)__ballot(1)) - 1;
+          const int gb = dbg_gen < 10 ? dbg_gen : 10, hb = dbg_hard < 4 ? dbg_hard : 4;
+          for (int g_ = 0; g_ <= 10; g_++) {
+            const unsigned long long m_ = __ballot(gb == g_);
+            if (m_ && lane == first) atomicAdd(&d.hdr->dbg[g_], (unsigned long long)__popcll(m_));
+          }
+          for (int h_ = 0; h_ <= 4; h_++) {
+            const unsigned long long m_ = __ballot(hb == h_);
+            if (m_ && lane == first) atomicAdd(&d.hdr->dbg[27 + h_], (unsigned long long)__popcll(m_));
+          }
+          const unsigned long long mj_ = __ballot(dbg_jump != 0);
+          if (mj_ && lane == first) atomicAdd(&d.hdr->dbg[11], (unsigned long long)__popcll(mj_));
+        }
         int mg_ = dbg_gen, mf_ = dbg_fast, ml_ = (int)(le - ls);
         for (int o = 32; o > 0; o >>= 1) {
           mg_ = max(mg_, __shfl_xor(mg_, o));
