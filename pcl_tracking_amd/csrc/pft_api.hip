@@ -50,6 +50,7 @@ struct pft_tracker {
   float* d_bbox6 = nullptr;
   uint32_t* d_crop_counts = nullptr;
   unsigned long long* d_crop_slots = nullptr;
+  uint32_t crop_epoch = 0;  // tag of the last one-pass crop launch (0 = what freshly allocated slots hold)
   float4* d_crop_pts = nullptr;
   int32_t* d_crop_idx = nullptr;
   uint32_t* d_words = nullptr;
@@ -690,7 +691,8 @@ static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32
                                          bool bbox_from_partials, bool keep_point_keys = false) {
   {
     ProfScope ps(t, PFT_K_CROP);
-    pftk_crop(t->stream, t->prm, d, bbox_from_partials);
+    if (++t->crop_epoch == 0) t->crop_epoch = 1;
+    pftk_crop(t->stream, t->prm, d, bbox_from_partials, t->crop_epoch);
   }
   if (t->cfg.exact_nearest) {  // NearestPairPointCloudCoherence: uniform grid + true nearest neighbour, no octree
     {

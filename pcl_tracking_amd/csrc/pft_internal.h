@@ -179,7 +179,8 @@ void pftk_likelihood_exact(hipStream_t s, const PftParams& p, const PftDev& d, u
 // table a/q when given), keeps the prefix the KL bound asks for, writes particles + matrices and the new p_active
 void pftk_resample_kld(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t epoch, pft_particle* out,
                        const int32_t* table_a, const double* table_q, int32_t* bins_out);
-void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d, bool bbox_from_partials);
+// epoch: a value that differs from the handle's previous crop launch (non-zero); tags the per-workgroup counts of the one-pass crop
+void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d, bool bbox_from_partials, uint32_t epoch);
 void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d);
 struct SortBufs {
   unsigned long long* keys[2];

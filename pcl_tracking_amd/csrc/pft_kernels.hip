@@ -441,13 +441,10 @@ void pftk_aabb(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_pa
                      lds_points, d.p_active);
   if (finalize) hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(512), 0, s, d.bbox_part, d.bbox_grid, d.bbox6);
 }
-void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d, bool from_part) {
+void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d, bool from_part, uint32_t epoch) {
   uint32_t nb = cdiv(d.N ? d.N : 1, 1024);
   const bool two_pass = getenv("PFT_CROP_TWO_PASS") != nullptr;  // A/B timing and cross-check (read per call: tests toggle it)
   if (!two_pass) {
-    static uint32_t epoch = 0;  // (shared by all handles: only has to differ from launch to launch on one stream)
-    epoch++;
-    if (epoch == 0) epoch = 1;  // 0 is what freshly allocated slots hold
     if (from_part)
       hipLaunchKernelGGL(k_crop_onepass<true>, dim3(nb), dim3(1024), 0, s, d.in_pts, d.N, d.bbox6, d.bbox_part, d.bbox_grid,
                          d.crop_slots, epoch, p.hsv_argorder, d.crop_pts, d.crop_idx, d.hdr, d.host_stat);
