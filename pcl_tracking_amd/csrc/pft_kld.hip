@@ -37,11 +37,17 @@ __global__ __launch_bounds__(KLD_THREADS) void k_resample_kld(PftParams p, PftDe
                                                               uint32_t tab_size, int32_t* __restrict__ bins_out) {
   __shared__ uint32_t scr[20];
   __shared__ uint32_t s_stop;
+  // up to 1024 candidates (the reference runs 500) the bin table, the bins and the per-candidate slots / counts live in
+  // LDS: the phases below are chains of dependent atomics and reads, and an LDS round trip is a tenth of an L2 one
+  __shared__ uint32_t s_tab[2048 + 2 * 1024];
+  __shared__ int32_t s_bins[6 * 1024];
+  __shared__ double cD[256], cE[256];
   PftHeader* hdr = d.hdr;
   const pft_particle* old = d.part_all;
   const uint32_t tid = threadIdx.x, maxn = p.kld_max, n_old = hdr->p_active;
-  uint32_t* tab = d.kld_table;
-  int32_t* bins = d.kld_bins;
+  const bool in_lds = maxn <= 1024u && tab_size <= 2048u;
+  uint32_t* tab = in_lds ? s_tab : d.kld_table;  // [tab_size] table, then [maxn] slots, then [maxn] counts
+  int32_t* bins = in_lds ? s_bins : d.kld_bins;
   for (uint32_t i = tid; i < tab_size; i += KLD_THREADS) tab[i] = KLD_EMPTY;
   if (tid == 0) s_stop = maxn;
   const pft_particle motion = hdr->motion;
@@ -54,6 +60,17 @@ __global__ __launch_bounds__(KLD_THREADS) void k_resample_kld(PftParams p, PftDe
   v.m = hdr->alias_m;
   v.nh = hdr->alias_nh;
   v.n = n_old;
+  if (!TABLE) {  // coarse levels of the two prefix arrays (as in k_resample)
+    v.sD = (v.m + 255u) / 256u;
+    v.sE = (v.nh + 255u) / 256u;
+    if (tid < 256u) {
+      if (v.m && tid * v.sD < v.m) cD[tid] = v.D[min((tid + 1u) * v.sD, v.m) - 1u];
+      if (v.nh && tid * v.sE < v.nh) cE[tid] = v.E[min((tid + 1u) * v.sE, v.nh) - 1u];
+    }
+    __syncthreads();
+    v.cD = cD;
+    v.cE = cE;
+  }
 
   // ---- all candidates ----
   for (uint32_t s = tid; s < maxn; s += KLD_THREADS) {
@@ -116,7 +133,7 @@ __global__ __launch_bounds__(KLD_THREADS) void k_resample_kld(PftParams p, PftDe
         }
         h = (h + 1u) & mask;  // another bin lives here
       }
-      d.kld_table[tab_size + s] = h;  // its slot, read again after the barrier
+      tab[tab_size + s] = h;  // its slot, read again after the barrier
     }
   }
   __threadfence_block();
@@ -127,7 +144,7 @@ __global__ __launch_bounds__(KLD_THREADS) void k_resample_kld(PftParams p, PftDe
   for (uint32_t s0 = 0; s0 < maxn; s0 += KLD_THREADS) {
     const uint32_t s = s0 + tid;
     uint32_t first = 0;
-    if (s < maxn) first = tab[d.kld_table[tab_size + s]] == s ? 1u : 0u;
+    if (s < maxn) first = tab[tab[tab_size + s]] == s ? 1u : 0u;
     uint32_t tot;
     const uint32_t k = carry + block_excl_scan<uint32_t>(first, scr, &tot) + first;  // distinct bins among 0..s
     carry += tot;
@@ -135,14 +152,14 @@ __global__ __launch_bounds__(KLD_THREADS) void k_resample_kld(PftParams p, PftDe
       const uint32_t n = s + 1u;
       const bool cont = n < maxn && (k < 2u || (double)n < kl_bound(k, p.kld_z, p.kld_eps));
       if (!cont) atomicMin(&s_stop, n);
-      d.kld_table[tab_size + maxn + s] = k;
+      tab[tab_size + maxn + s] = k;
     }
   }
   __syncthreads();
   if (tid == 0) {
     const uint32_t n = s_stop;
     hdr->p_active = n;
-    hdr->kld_k = d.kld_table[tab_size + maxn + n - 1u];
+    hdr->kld_k = tab[tab_size + maxn + n - 1u];
   }
   if (bins_out) {
     for (uint32_t i = tid; i < 6u * maxn; i += KLD_THREADS) bins_out[i] = bins[i];
