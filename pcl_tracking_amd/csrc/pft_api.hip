@@ -727,7 +727,7 @@ static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32
       pftk_octree_sorted(t->stream, t->prm, db, t->sort, d.N, npass);
     }
     else
-      pftk_octree(t->stream, t->prm, db);
+      pftk_octree(t->stream, t->prm, db, last_n);
   }
   {
     ProfScope ps(t, PFT_K_LIKELIHOOD);

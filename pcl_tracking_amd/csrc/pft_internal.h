@@ -181,7 +181,7 @@ void pftk_resample_kld(hipStream_t s, const PftParams& p, const PftDev& d, uint3
                        const int32_t* table_a, const double* table_q, int32_t* bins_out);
 // epoch: a value that differs from the handle's previous crop launch (non-zero); tags the per-workgroup counts of the one-pass crop
 void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d, bool bbox_from_partials, uint32_t epoch);
-void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d);
+void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t expected_points);
 struct SortBufs {
   unsigned long long* keys[2];
   uint32_t* vals[2];

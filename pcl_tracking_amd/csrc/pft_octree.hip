@@ -533,7 +533,8 @@ __device__ __forceinline__ void build_regs(const PftParams& prm, const PftDev& d
   }
 }
 
-__global__ __launch_bounds__(PFT_BUILD_THREADS) void k_octree_build(PftParams prm, PftDev d, uint32_t lds_bytes) {
+__global__ __launch_bounds__(PFT_BUILD_THREADS) void k_octree_build(PftParams prm, PftDev d, uint32_t lds_bytes,
+                                                                    int copy_leaf_pts) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ BuildSh S;
   PftHeader* hdr = d.hdr;
@@ -581,6 +582,10 @@ __global__ __launch_bounds__(PFT_BUILD_THREADS) void k_octree_build(PftParams pr
   STAMP(7);
   const int D = S.depth;
   const bool ok = n > 0 && !S.err && D > 0;
+  if (copy_leaf_pts && ok) {  // small crops: the leaf-ordered point records are copied here instead of by k_leaf_gather
+    __threadfence_block();    // (a launch costs more than moving a few thousand records through one CU)
+    for (uint32_t pos = tid; pos < n; pos += blockDim.x) d.leaf_pts[pos] = d.crop_pts[d.leaf_order[pos]];
+  }
 
   // ---- voxel-centre tables: centre(level l, key k) = (float)((k + 0.5) * res*2^(D-l) + min) ----
   const int use_table = (ok && D <= PFT_TABLE_MAX_DEPTH) ? 1 : 0;
@@ -640,7 +645,7 @@ __global__ __launch_bounds__(256) void k_leaf_gather(PftDev d) {
   d.leaf_pts[pos] = d.crop_pts[d.leaf_order[pos]];
 }
 
-void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d) {
+void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t expected_points) {
   static bool attr_set = false;
   // static LDS of the kernel (BuildSh ~2.6 KB, the dense top-level arrays 5 KB): leave 10 KB out of the dynamic request
   const uint32_t lds = ((uint32_t)pftk_max_lds_bytes() - 10240u) & ~15u;
@@ -649,7 +654,10 @@ void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d) {
                         (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_octree_build, dim3(1), dim3(PFT_BUILD_THREADS), lds, s, p, d, lds);
+  // the crop size of the previous iteration decides who copies the leaf records (either way is correct for any size)
+  const int copy_in_kernel = expected_points <= 5000u ? 1 : 0;
+  hipLaunchKernelGGL(k_octree_build, dim3(1), dim3(PFT_BUILD_THREADS), lds, s, p, d, lds, copy_in_kernel);
   // at most PFT_SORTED_BUILD_MIN-ish points reach this builder in practice, but any crop (<= N) is legal
-  hipLaunchKernelGGL(k_leaf_gather, dim3((d.N + 255u) / 256u ? (d.N + 255u) / 256u : 1u), dim3(256), 0, s, d);
+  if (!copy_in_kernel)
+    hipLaunchKernelGGL(k_leaf_gather, dim3((d.N + 255u) / 256u ? (d.N + 255u) / 256u : 1u), dim3(256), 0, s, d);
 }
