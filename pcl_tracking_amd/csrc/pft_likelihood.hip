@@ -67,7 +67,9 @@ __device__ __forceinline__ bool face_violation(uint32_t kx, uint32_t ky, uint32_
   return v;
 }
 
-template <bool USE_TAB, bool FAST, bool DEBUG_NN, bool LEAF16, typename WordPtr>
+// LEAF: where the leaf level's start offsets come from -- 0: the node words themselves (W), 1: u16 array in LDS,
+// 2: the u32 words in HBM / L2 (the branch levels alone are in LDS)
+template <bool USE_TAB, bool FAST, bool DEBUG_NN, int LEAF, typename WordPtr>
 __device__ __forceinline__ void likelihood_items(const PftParams& prm, const PftDev& d, const LikCtx& cx, WordPtr W,
                                                  uint32_t n_particles, int D, uint32_t n_crop,
                                                  const double omin[3], int abl) {
@@ -217,10 +219,13 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
       }
       // ---- leaf scan: first strictly-smaller wins (insertion order) ----
       uint32_t ls, le;
-      if (LEAF16) {  // leaf starts as u16 in LDS (cropped clouds below 65536 points)
+      if (LEAF == 1) {  // leaf starts as u16 in LDS (cropped clouds below 65536 points)
         const uint32_t li = node - cx.leaf0;
         ls = cx.leaf16[li];
         le = cx.leaf16[li + 1u];
+      } else if (LEAF == 2) {
+        ls = d.words[node];
+        le = d.words[node + 1];
       } else {
         ls = W[node];
         le = W[node + 1];
@@ -365,7 +370,10 @@ __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * 
   // keep the jump table and hold only the top levels of the tree in LDS (HybridWords).
   const bool fits_with_jump = (size_t)used + jump_bytes + branch_bytes + leaf_bytes <= (size_t)lds_bytes;
   const bool fits_without_jump = (size_t)used + branch_bytes + leaf_bytes <= (size_t)lds_bytes;
-  if (!fits_with_jump && fits_without_jump) {
+  // (deep trees: 24 KiB of centre tables at depth 10) the branch levels and the jump table in LDS, the leaf starts
+  // from L2: 228 us against 242 us without the jump table and 238 us with the words split at an arbitrary index
+  const bool branch_only = !fits_with_jump && leaf16 && (size_t)used + jump_bytes + branch_bytes <= (size_t)lds_bytes;
+  if (!fits_with_jump && fits_without_jump && !branch_only) {
     J = 0;
     jump_bytes = 0;
   }
@@ -373,8 +381,8 @@ __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * 
   used += jump_bytes;
   uint32_t* lwords = reinterpret_cast<uint32_t*>(smem + used);
   uint16_t* lleaf = reinterpret_cast<uint16_t*>(smem + used + branch_bytes);
-  const bool words_in_lds = (size_t)used + branch_bytes + leaf_bytes <= (size_t)lds_bytes;
-  const uint32_t n_lds_words = words_in_lds ? 0u : min(n_words, (lds_bytes - used) / 4u);
+  const bool words_in_lds = !branch_only && (size_t)used + branch_bytes + leaf_bytes <= (size_t)lds_bytes;
+  const uint32_t n_lds_words = (words_in_lds || branch_only) ? 0u : min(n_words, (lds_bytes - used) / 4u);
 
   for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
     lut_h[i] = (float)i / 180.0f;
@@ -386,10 +394,10 @@ __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * 
     uint32_t* dst = reinterpret_cast<uint32_t*>(ljump);
     for (uint32_t i = threadIdx.x; i < jump_bytes / 4u; i += blockDim.x) dst[i] = src[i];
   }
-  if (words_in_lds) {
+  if (words_in_lds || branch_only) {
     const uint32_t nb = leaf16 ? leaf_start : n_words;
     for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) lwords[i] = d.words[i];
-    if (leaf16)
+    if (leaf16 && !branch_only)
       for (uint32_t i = threadIdx.x; i <= n_leaves; i += blockDim.x) lleaf[i] = (uint16_t)d.words[leaf_start + i];
   } else {
     for (uint32_t i = threadIdx.x; i < n_lds_words; i += blockDim.x) lwords[i] = d.words[i];
@@ -413,33 +421,39 @@ __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * 
   cx.ncell = (float)(1u << (D > 0 ? D : 0));
   cx.leaf0 = hdr->leaf_start;
   cx.leaf16 = lleaf;
-  if (words_in_lds && leaf16) {  // node words addressed as LDS (ds_read), not through a generic pointer
+  if (branch_only) {
     const uint32_t* W = lwords;
     if (fast)
-      likelihood_items<true, true, DEBUG_NN, true>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
-    else if (use_tab)
-      likelihood_items<true, false, DEBUG_NN, true>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+      likelihood_items<true, true, DEBUG_NN, 2>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
     else
-      likelihood_items<false, false, DEBUG_NN, true>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+      likelihood_items<true, false, DEBUG_NN, 2>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+  } else if (words_in_lds && leaf16) {  // node words addressed as LDS (ds_read), not through a generic pointer
+    const uint32_t* W = lwords;
+    if (fast)
+      likelihood_items<true, true, DEBUG_NN, 1>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+    else if (use_tab)
+      likelihood_items<true, false, DEBUG_NN, 1>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+    else
+      likelihood_items<false, false, DEBUG_NN, 1>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
   } else if (words_in_lds) {
     const uint32_t* W = lwords;
     if (fast)
-      likelihood_items<true, true, DEBUG_NN, false>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+      likelihood_items<true, true, DEBUG_NN, 0>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
     else if (use_tab)
-      likelihood_items<true, false, DEBUG_NN, false>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+      likelihood_items<true, false, DEBUG_NN, 0>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
     else
-      likelihood_items<false, false, DEBUG_NN, false>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+      likelihood_items<false, false, DEBUG_NN, 0>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
   } else {
     HybridWords W;
     W.lds = (const __attribute__((address_space(3))) uint32_t*)lwords;
     W.glob = d.words;
     W.n_lds = n_lds_words;
     if (fast)
-      likelihood_items<true, true, DEBUG_NN, false>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+      likelihood_items<true, true, DEBUG_NN, 0>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
     else if (use_tab)
-      likelihood_items<true, false, DEBUG_NN, false>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+      likelihood_items<true, false, DEBUG_NN, 0>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
     else
-      likelihood_items<false, false, DEBUG_NN, false>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+      likelihood_items<false, false, DEBUG_NN, 0>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
   }
 }
 

@@ -441,6 +441,48 @@ def test_compute_other_iteration_counts(gpu, orc, data, iters):
             assert abs(float(rg[k]) - float(ro[k])) < 1e-4, (f, k)
 
 
+def test_eval_weights_deep_tree_branch_levels_only_in_lds(gpu, orc, data):
+    """a depth-10 tree (5 mm leaves) whose centre tables, jump table and branch levels fit the likelihood kernel's 80 KiB
+    of LDS but whose leaf starts do not: the kernel then reads the leaf starts from L2 (third LDS layout of
+    pft_likelihood.hip); the layout is asserted from the tree's sizes so that this case keeps covering it"""
+    P, res = 64, 0.005
+    model, cloud = scene.make_model(2048), scene.make_scene(50000)
+    g = gpu.make_reference_tracker(particle_num=P, seed=1)
+    coh = gpu.ApproxNearestPairPointCloudCoherence()
+    coh.addPointCoherence(gpu.DistanceCoherence())
+    hc = gpu.HSVColorCoherence()
+    hc.setWeight(0.1)
+    coh.addPointCoherence(hc)
+    coh.setSearchMethod(gpu.OctreeSearch(res))
+    coh.setMaximumDistance(0.1)
+    g.setCloudCoherence(coh)
+    o = orc.Tracker(orc.default_config(particle_num=P, seed=1, threads=0, emulate_pcl_alloc=0, octree_resolution=res))
+    for ref, tr, inp in ((g.setReferenceCloud, g.setTrans, g.setInputCloud), (o.set_reference, o.set_trans, o.set_input)):
+        ref(model)
+        tr(scene.initial_trans())
+        inp(cloud)
+    rng = np.random.default_rng(3)
+    gt = scene.model_gt_pose()
+    p = np.zeros(P, scene.PARTICLE_DTYPE)
+    for k, name in enumerate(("x", "y", "z")):
+        p[name] = gt[k] + rng.normal(0, 0.2, P)
+    for k, name in enumerate(("roll", "pitch", "yaw")):
+        p[name] = gt[3 + k] + rng.normal(0, 0.2, P)
+    p["w"] = 1.0
+    p["weight"] = 1.0 / P
+    G = g.evalWeights(p, want_nn=True)
+    O = o.eval_weights(p, want_nn=True, mats=g.debugPoseToMatrix(p))
+    D, nl, nw = G["octree_depth"], G["n_leaves"], G["n_words"]
+    leaf_start = nw - nl - 1
+    base = 2048 + 3 * (2 << D) * 4 + (2 << 12)
+    assert D == O["octree_depth"] == 10
+    assert base + leaf_start * 4 <= 80 * 1024 < base + leaf_start * 4 + (nl + 1) * 2, (D, leaf_start, nl)
+    np.testing.assert_array_equal(G["crop_idx"], O["crop_idx"])
+    np.testing.assert_array_equal(G["nn_idx"], O["nn_idx"])
+    np.testing.assert_array_equal(G["nn_d2"], O["nn_d2"])
+    assert ulp_diff(G["raw"], O["raw"]).max() <= 1
+
+
 def test_crop_one_pass_and_two_pass_agree(gpu, orc, data, monkeypatch):
     """the order-preserving crop in one launch (ticketed workgroups) against the count + scatter pair and the oracle"""
     p = particles_around(data["gt"], 96, 17, sig_t=0.2, sig_r=0.5)  # a wide box: the crop keeps most of the cloud
