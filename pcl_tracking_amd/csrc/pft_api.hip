@@ -438,6 +438,7 @@ extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
   p.M = 0;
   p.nchunk = 1;
   p.ref_chunk = PFT_REF_CHUNK;
+  p.split_last = 0;
   p.kld = cfg->kld_adaptive ? 1u : 0u;
   p.kld_max = (uint32_t)cfg->maximum_particle_num;
   p.kld_z = pft_kld_normal_quantile(cfg->kld_delta);
@@ -564,6 +565,13 @@ extern "C" int pft_set_reference(pft_tracker* t, const pft_point_xyzrgba* pts, s
   }
   t->prm.nchunk = (uint32_t)((n + t->prm.ref_chunk - 1) / t->prm.ref_chunk);
   if (t->prm.nchunk == 0) t->prm.nchunk = 1;
+  // the items a launch ends with decide how long its last waves run alone: the last chunk is cut in two halves, and
+  // the halves of all particles are handed out after the full-size items (approximate search only)
+  t->prm.split_last = 0;
+  if (!t->cfg.exact_nearest && t->prm.ref_chunk >= 128u && n % t->prm.ref_chunk == 0 && t->prm.nchunk >= 2u) {
+    t->prm.split_last = t->prm.ref_chunk >= 256u ? 4u : 2u;  // sub-items of at least 64 points (one round of a wave)
+    t->prm.nchunk += t->prm.split_last - 1u;
+  }
   dfree(t->d_partial);
   HIPCHK(t, dalloc(&t->d_partial, (size_t)(t->prm.kld ? t->Pcap : t->prm.P_local) * t->prm.nchunk));
   if (n) {

@@ -55,6 +55,7 @@ struct PftParams {  // immutable per handle, passed by value to kernels
   uint32_t P_total, P_local, id_offset;
   uint32_t M, nchunk;
   uint32_t ref_chunk;  // reference points per likelihood work item: 64 .. PFT_REF_CHUNK, smaller when there are few particles
+  uint32_t split_last;  // s > 0: the last ref_chunk points of the cloud form s items of ref_chunk / s points, handed out last (shorter tail)
   // KLD-adaptive variant (KLDAdaptiveParticleFilterOMPTracker, auto_tracking.cpp:207-222)
   uint32_t kld;          // 1: the particle count changes at every resample and lives in PftHeader::p_active
   uint32_t kld_max;      // maximum_particle_number_

@@ -75,7 +75,6 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
                                                  const double omin[3], int abl) {
   const int lane = lane_id(), w = wave_id(), nw = blockDim.x >> 6;
   const uint32_t M = prm.M, nchunk = prm.nchunk;
-  const uint32_t n_items = n_particles * nchunk;
   // Work distribution.  The cost of an item depends on where its queries land, and with a static round-robin the
   // slowest wave sets the launch time (mean wave busy 219 us, launch 250 us).  The workgroups form PFT_LIK_GROUPS
   // groups (blockIdx % groups: spread over the XCDs); a group owns a contiguous range of items; a wave's first item is
@@ -85,9 +84,13 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
   const uint32_t gq = gridDim.x / G, gr = gridDim.x % G;  // groups below gr have gq + 1 workgroups, the others gq
   const uint32_t wgs_in_grp = gq + (grp < gr ? 1u : 0u), waves_in_grp = wgs_in_grp * (uint32_t)nw;
   const uint32_t wgs_before = grp * gq + min(grp, gr);
-  // the group's share of the items is proportional to its workgroups
-  const uint32_t it_begin = (uint32_t)((unsigned long long)n_items * wgs_before / gridDim.x);
-  const uint32_t it_end = (uint32_t)((unsigned long long)n_items * (wgs_before + wgs_in_grp) / gridDim.x);
+  // the group's share of the particles is proportional to its workgroups; inside the group the full-size chunks of all
+  // its particles come first, then (split_last) the small chunks that end the reference cloud
+  const uint32_t pb = (uint32_t)((unsigned long long)n_particles * wgs_before / gridDim.x);
+  const uint32_t pe = (uint32_t)((unsigned long long)n_particles * (wgs_before + wgs_in_grp) / gridDim.x);
+  const uint32_t np_grp = pe - pb, nbig = prm.split_last ? nchunk - prm.split_last : nchunk, nsmall = nchunk - nbig;
+  const uint32_t small_len = prm.split_last ? prm.ref_chunk / prm.split_last : 0u;
+  const uint32_t it_begin = 0u, it_end = np_grp * nchunk, big_items = np_grp * nbig;
   const uint32_t lw = (blockIdx.x / G) * (uint32_t)nw + (uint32_t)w;
   uint32_t* ctr = &d.hdr->lik_ctr[grp * 16u];
   const double res = prm.res;
@@ -98,13 +101,25 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
     // the work item is wave-uniform: said explicitly, so the particle's matrix is fetched with scalar loads and
     // lives in SGPRs
     const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item_v);
-    const uint32_t pi = item / nchunk, ch = item % nchunk;
+    uint32_t pi, ch, cstart, clen;
+    if (item < big_items) {
+      pi = pb + item / nbig;
+      ch = item % nbig;
+      cstart = ch * prm.ref_chunk;
+      clen = prm.ref_chunk;
+    } else {
+      const uint32_t r = item - big_items;
+      pi = pb + r / nsmall;
+      ch = nbig + r % nsmall;
+      cstart = nbig * prm.ref_chunk + (r % nsmall) * small_len;
+      clen = small_len;
+    }
     float T[12];
     load_matrix(d.mats, pi, T);
     double val = 0.0;
     unsigned long long st_q = 0, st_s = 0;
-    const uint32_t jend = min(M, (ch + 1) * prm.ref_chunk);
-    const uint32_t j0 = ch * prm.ref_chunk + lane;
+    const uint32_t jend = min(M, cstart + clen);
+    const uint32_t j0 = cstart + lane;
     float4 rnext = j0 < jend ? d.ref_xyz[j0] : make_float4(0, 0, 0, 0);
     for (uint32_t j = j0; j < jend; j += WAVE) {
       const float4 r = rnext;
