@@ -141,14 +141,25 @@ __global__ __launch_bounds__(1024) void k_aabb(const float4* __restrict__ ref, u
   for (uint32_t pi = gw; pi < n_particles; pi += tw) {
     float T[12];
     load_matrix(mats, pi, T);
+    // x' = ((T0 x + T1 y) + T2 z) + T3: the translation is added once per particle, after the reduction -- float
+    // addition of a constant is monotone, so min / max over the points of fl(s + T3) equal fl(min / max s + T3) exactly
+    float pmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, pmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
 #pragma unroll 4
     for (uint32_t j = lane; j < M; j += WAVE) {
       float4 r = src[j];
-      float x, y, z;
-      xform(T, r.x, r.y, r.z, x, y, z);
-      mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
-      mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
-      mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
+      const float x = T[0] * r.x + T[1] * r.y + T[2] * r.z;
+      const float y = T[4] * r.x + T[5] * r.y + T[6] * r.z;
+      const float z = T[8] * r.x + T[9] * r.y + T[10] * r.z;
+      pmn[0] = fminf(pmn[0], x); pmx[0] = fmaxf(pmx[0], x);
+      pmn[1] = fminf(pmn[1], y); pmx[1] = fmaxf(pmx[1], y);
+      pmn[2] = fminf(pmn[2], z); pmx[2] = fmaxf(pmx[2], z);
+    }
+    if (lane < M) {  // (lanes without a point keep their neutral values)
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        mn[k] = fminf(mn[k], pmn[k] + T[4 * k + 3]);
+        mx[k] = fmaxf(mx[k], pmx[k] + T[4 * k + 3]);
+      }
     }
   }
 #pragma unroll
