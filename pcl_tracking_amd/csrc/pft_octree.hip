@@ -180,6 +180,7 @@ template <int K>
 struct RegStore {
   typedef uint32_t key_t;
   static constexpr int B = 10;
+  static constexpr bool MORTON = true;  // 30-bit keys are kept bit-interleaved: a level's child index is one bit-field extract
   uint32_t key[K], node[K];
   __device__ RegStore(const PftDev&) {}
   template <class F>
@@ -198,6 +199,7 @@ template <int K>
 struct HybridStore {
   typedef uint32_t key_t;
   static constexpr int B = 10;
+  static constexpr bool MORTON = true;
   uint32_t key[K], node[K];
   uint32_t* gkey;
   uint32_t* gnode;
@@ -217,6 +219,7 @@ struct HybridStore {
 struct GlobStore {
   typedef unsigned long long key_t;
   static constexpr int B = 21;
+  static constexpr bool MORTON = false;  // (x << 42 | y << 21 | z)
   unsigned long long* key;
   uint32_t* node;
   __device__ GlobStore(const PftDev& d) : key(d.pt_key64), node(d.pt_node) {}
@@ -227,10 +230,21 @@ struct GlobStore {
   }
 };
 
-template <class KT, int B>
+// child index (x << 2 | y << 1 | z) of a key at bit `bit` of its three coordinates
+template <class KT, int B, bool MORTON>
 __device__ __forceinline__ uint32_t key_child(KT k, int bit) {
+  if (MORTON) return (uint32_t)(k >> (3 * bit)) & 7u;
   return (uint32_t)(((k >> (2 * B + bit)) & 1) << 2) | (uint32_t)(((k >> (B + bit)) & 1) << 1) |
          (uint32_t)((k >> bit) & 1);
+}
+
+// 10 bits -> every third bit (bit b -> 3b)
+__device__ __forceinline__ uint32_t spread3_10(uint32_t x) {
+  x = (x | (x << 16)) & 0x030000FFu;
+  x = (x | (x << 8)) & 0x0300F00Fu;
+  x = (x | (x << 4)) & 0x030C30C3u;
+  x = (x | (x << 2)) & 0x09249249u;
+  return x;
 }
 
 // LDSW: node words and the leaf scratch list live in LDS (typed pointers: ds_* instructions); otherwise in HBM.
@@ -286,7 +300,10 @@ __device__ __forceinline__ bool build_tree(const PftParams& prm, const PftDev& d
       d.pt_key[3 * (size_t)i + 1] = ky;
       d.pt_key[3 * (size_t)i + 2] = kz;
     }
-    key = ((key_t)kx << (2 * B)) | ((key_t)ky << B) | (key_t)kz;
+    if (Store::MORTON)
+      key = (key_t)((spread3_10(kx) << 2) | (spread3_10(ky) << 1) | spread3_10(kz));
+    else
+      key = ((key_t)kx << (2 * B)) | ((key_t)ky << B) | (key_t)kz;
     node = 0;
   });
 
@@ -304,7 +321,10 @@ __device__ __forceinline__ bool build_tree(const PftParams& prm, const PftDev& d
     uint32_t* dn_cnt = S.dn_cnt;
     st.each(n, [&](uint32_t, key_t& key, uint32_t& node) {  // Morton index of the point's level-J cell; its occupancy bit
       uint32_t mj = 0;
-      for (int l = 0; l < J; l++) mj = (mj << 3) | key_child<key_t, B>(key, D - 1 - l);
+      if (Store::MORTON)
+        mj = (uint32_t)(key >> (3 * (D - J)));  // the top J digits of the interleaved key
+      else
+        for (int l = 0; l < J; l++) mj = (mj << 3) | key_child<key_t, B, Store::MORTON>(key, D - 1 - l);
       node = mj;
       const uint32_t bt = 1u << (mj & 31u);
       if (!(dn_bits[J][mj >> 5] & bt)) atomicOr(&dn_bits[J][mj >> 5], bt);
@@ -393,12 +413,12 @@ __device__ __forceinline__ bool build_tree(const PftParams& prm, const PftDev& d
     st.each(n, [&](uint32_t, key_t& key, uint32_t& node) {
       if (l > l0) {  // move to the level-l node chosen by the previous level's bits
         uint32_t w = W[node];
-        uint32_t cp = key_child<key_t, B>(key, bit + 1);
+        uint32_t cp = key_child<key_t, B, Store::MORTON>(key, bit + 1);
         node = (w >> 8) + __popc(w & 0xffu & ((1u << cp) - 1u));
       }
       // near the root thousands of points share a word: test first, so only the first arrivals pay for the
       // (same-address, serialised) LDS atomic
-      const uint32_t cb = 1u << key_child<key_t, B>(key, bit);
+      const uint32_t cb = 1u << key_child<key_t, B, Store::MORTON>(key, bit);
       if (!(W[node] & cb)) atomicOr(&W[node], cb);
     });
     __syncthreads();
@@ -457,7 +477,7 @@ __device__ __forceinline__ bool build_tree(const PftParams& prm, const PftDev& d
   const uint32_t leaf_start = S.lvl[D], n_leaves = S.lvl[D + 1] - leaf_start;
   st.each(n, [&](uint32_t, key_t& key, uint32_t& node) {
     uint32_t w = W[node];
-    uint32_t c = key_child<key_t, B>(key, 0);
+    uint32_t c = key_child<key_t, B, Store::MORTON>(key, 0);
     uint32_t leaf = (w >> 8) + __popc(w & 0xffu & ((1u << c) - 1u));
     node = leaf;
     key = (key_t)atomicAdd(&W[leaf], 1u);  // arrival slot inside the leaf (the key is no longer needed)
