@@ -121,7 +121,12 @@ __device__ __forceinline__ void box_replay(BuildSh& S, const float4* __restrict_
     for (uint32_t c = 0; c < PFT_REPLAY_HEAD / WAVE; c++) q[c] = pts[min(c * WAVE + tid, n - 1u)];
     uint32_t cur = 1;
     bool stop = false;
-    double mn[3] = {S.mn[0], S.mn[1], S.mn[2]}, mx[3] = {S.mx[0], S.mx[1], S.mx[2]};  // re-read only after an event
+    // the box lives in registers, identical in every lane: a growth event is replayed by all lanes on the broadcast
+    // point (no LDS round trips on the serial path); lane 0 records the event for the key phase
+    double mn[3] = {S.mn[0], S.mn[1], S.mn[2]}, mx[3] = {S.mx[0], S.mx[1], S.mx[2]};
+    int depth = S.depth, ngrow = S.ngrow;
+    uint32_t err = S.err;
+    const double epsd = (double)FLT_EPSILON;
 #pragma unroll
     for (uint32_t c = 0; c < PFT_REPLAY_HEAD / WAVE; c++) {
       const uint32_t gi = c * WAVE + tid;
@@ -131,17 +136,49 @@ __device__ __forceinline__ void box_replay(BuildSh& S, const float4* __restrict_
         const unsigned long long bal = __ballot(viol);
         if (!bal) break;
         const int f = __ffsll((long long)bal) - 1;
-        const float4 pf = make_float4(__shfl(p.x, f), __shfl(p.y, f), __shfl(p.z, f), 0.0f);
-        if (tid == 0) box_grow(S, pf, c * WAVE + (uint32_t)f, res);
-        cur = c * WAVE + (uint32_t)f + 1u;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // lane 0's LDS writes -> the wave's next reads
-        __builtin_amdgcn_wave_barrier();
-        for (int a = 0; a < 3; a++) {
-          mn[a] = S.mn[a];
-          mx[a] = S.mx[a];
+        const float px = __shfl(p.x, f), py = __shfl(p.y, f), pz = __shfl(p.z, f);
+        const uint32_t idx = c * WAVE + (uint32_t)f;
+        for (;;) {  // adoptBoundingBoxToPoint, as box_grow()
+          const bool lx = px < mn[0], ly = py < mn[1], lz = pz < mn[2];
+          const bool ux = px >= mx[0], uy = py >= mx[1], uz = pz >= mx[2];
+          if (!(lx || ly || lz || ux || uy || uz)) break;
+          if (ngrow >= PFT_MAX_GROW || depth >= PFT_MAX_DEPTH) {
+            err |= 2u;
+            break;
+          }
+          double side = (double)(1u << depth) * res;
+          if (tid == 0) {
+            S.gidx[ngrow] = idx;
+            S.gshift[ngrow] = (ux ? 0u : 1u) | (uy ? 0u : 2u) | (uz ? 0u : 4u);
+            S.gold[ngrow] = (uint32_t)depth;
+          }
+          if (!ux) mn[0] -= side;
+          if (!uy) mn[1] -= side;
+          if (!uz) mn[2] -= side;
+          depth++;
+          side = (double)(1u << depth) * res - epsd;
+          mx[0] = mn[0] + side;
+          mx[1] = mn[1] + side;
+          mx[2] = mn[2] + side;
+          if (tid == 0) {
+            S.gmin[ngrow + 1][0] = mn[0];
+            S.gmin[ngrow + 1][1] = mn[1];
+            S.gmin[ngrow + 1][2] = mn[2];
+          }
+          ngrow++;
         }
-        if (S.err) stop = true;
+        cur = idx + 1u;
+        if (err) stop = true;
       }
+    }
+    if (tid == 0) {
+      for (int a = 0; a < 3; a++) {
+        S.mn[a] = mn[a];
+        S.mx[a] = mx[a];
+      }
+      S.depth = depth;
+      S.ngrow = ngrow;
+      S.err = err;
     }
     if (tid == 0) S.cur = head;
   }
