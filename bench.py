@@ -1,12 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the tracking hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
 
-A "step" is one tracked frame = one pft_compute(): iteration_num x [resample, weight, update] over one
-batch of synthetic input (BASELINE.json configs[1]: 2 048-point model vs 50 000-point cloud, 8 192
-particles per GPU, single frame looped, filter left running).  Inputs are resident in HBM when the
-timed region starts.  Rank 0 prints ONE JSON line.  value = P_total * N_points / t_frame.
+N > 1: one rank per GPU over RCCL.  Under a launcher (RANK / WORLD_SIZE in the environment, e.g.
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) this process is one rank; invoked
+directly with --gpus N > 1 it starts the N ranks itself (torch.distributed.run as a child process, before anything
+here touches a GPU), relays their one JSON line and exits with their code.  It never falls back to fewer ranks:
+a mismatch between --gpus, WORLD_SIZE and the visible GPUs is an error exit.
+
+A "step" is one tracked frame = one pft_compute(): iteration_num x [resample, weight, update] over one batch of
+synthetic input (BASELINE.json configs[1]: 2 048-point model vs 50 000-point cloud, 8 192 particles per GPU, single
+frame looped).  The headline workload is STATIONARY: after the warm-up frames the filter state is checkpointed in
+HBM and every timed step replays the same frame from it (one small restore kernel per step, inside the timed
+region), so the number does not depend on --steps / --warmup; the free-running filter is timed beside it
+("running").  Inputs are resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
+value = P_total * N_points / t_frame.
 """
 import argparse
 import json
@@ -21,6 +30,9 @@ P_PER_GPU = 8192
 M_MODEL = 2048
 N_CLOUD = 50000
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# same guide, "CU" section + constants table: 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles at
+# 2.4 GHz => 1024 x 2.4e9 / 2 wave-instructions per second, chip-wide
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2.0
 
 
 def parse():
@@ -35,11 +47,70 @@ def parse():
     ap.add_argument("--objects", type=int, default=1, help="independent trackers, one HIP stream each (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frontend", action="store_true", help="skip the PassThrough + ApproximateVoxelGrid side measurement")
-    ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--cpu-frames", type=int, default=20, help="CPU baseline: timed frames wanted (SURVEY 8d: >= 20)")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="CPU baseline: stop early after this much timed work")
+    ap.add_argument("--running", action="store_true", help="headline = the free-running filter instead of the replayed frame")
     return ap.parse_args()
 
 
-def cpu_baseline(model, cloud, trans, P, threads, pcl_alloc=1):
+def workload_label(P_local, M, N, organized, objects, world):
+    """which BASELINE.json configuration this invocation is (the headline metric is quoted on configs[1])"""
+    shape = "%d-pt model vs %d-pt %s cloud, %d particles/GPU, 2 iterations/frame, single frame looped" % (
+        M, N, "organized (no downsample)" if organized else "voxel-downsampled", P_local)
+    if objects == 1 and M == M_MODEL and not organized and N == N_CLOUD and P_local == P_PER_GPU:
+        if world == 1:
+            return "BASELINE configs[1]: " + shape
+        if world == 8:
+            return "BASELINE configs[3]: %d particles sharded %d/GPU over %d GPUs, " % (P_local * world, P_local, world) + shape
+        return "BASELINE configs[3] shape at %d GPUs (%d particles sharded %d/GPU): " % (world, P_local * world, P_local) + shape
+    if objects == 1 and organized and N == 307200 and P_local == 16384 and world == 1:
+        return "BASELINE configs[2]: " + shape
+    if objects == 4 and N == 200000 and P_local == P_PER_GPU and not organized:
+        return "BASELINE configs[4]%s: 4 independent model clouds, one handle + HIP stream each, shared cloud; %s" % (
+            "" if world == 8 else " shape on %d GPU(s)" % world, shape)
+    return "custom (not a BASELINE configuration): %d object(s), %s" % (objects, shape)
+
+
+def spawn_ranks_if_needed():
+    """`python bench.py --gpus N` with N > 1 and no launcher: start the N ranks as a child torch.distributed.run
+    BEFORE this process touches a GPU, relay its output, exit with its code.  Never fewer ranks than asked for."""
+    import subprocess
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if "RANK" in os.environ or world_env is not None:
+        if int(world_env or "1") != ARGS.gpus:
+            sys.stderr.write("bench.py: --gpus %d but the launcher set WORLD_SIZE=%s: refusing to run\n" % (ARGS.gpus, world_env))
+            sys.exit(2)
+        return
+    if ARGS.gpus <= 1:
+        return
+    import torch  # device_count() reads the driver's list and does not initialise the GPU
+
+    ndev = torch.cuda.device_count()
+    if ndev < ARGS.gpus:
+        sys.stderr.write("bench.py: --gpus %d but %d GPU(s) are visible on this machine: refusing to run fewer ranks "
+                         "and report them as %d\n" % (ARGS.gpus, ndev, ARGS.gpus))
+        sys.exit(2)
+    try:  # the ranks rely on the shipped / freshly built library (no rebuild under each other's feet)
+        from pcl_tracking_amd import build as _hip_build
+
+        _hip_build.build()
+    except Exception as e:
+        sys.stderr.write("bench: rebuild skipped (%s)\n" % e)
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ARGS.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
+
+
+def cpu_baseline(model, cloud, trans, P, threads, pcl_alloc=1, frames=20, seconds=30.0, warm=3):
     """the oracle (CPU restatement of the PCL OMP path, PCL-structured: per-particle clouds materialised,
     pointer octree rebuilt per iteration, per-query index-vector allocation) timed on the host cores.
     Test infrastructure used here only as the reported baseline."""
@@ -51,15 +122,16 @@ def cpu_baseline(model, cloud, trans, P, threads, pcl_alloc=1):
     tr.set_reference(model)
     tr.set_trans(trans)
     tr.set_input(cloud)
-    tr.compute()  # warm-up frame (includes initParticles)
+    for _ in range(warm):  # warm-up frames (the first includes initParticles)
+        tr.compute()
     times = []
     stages = None
-    for _ in range(max(1, ARGS.cpu_frames)):
+    while len(times) < max(1, frames) and (len(times) < 3 or sum(times) < seconds):
         t0 = time.perf_counter()
         tr.compute()
         times.append(time.perf_counter() - t0)
         stages = tr.stage_times()
-    return min(times), sorted(times)[len(times) // 2], stages
+    return min(times), sorted(times)[len(times) // 2], stages, len(times)
 
 
 def frontend_measurement(dev, with_cpu):
@@ -141,135 +213,186 @@ def reference_operating_point(model, cloud, trans, dev, with_cpu):
 
 
 def main():
+    spawn_ranks_if_needed()  # --gpus N > 1 without a launcher: becomes the parent of N ranks and never returns
+
     import numpy as np
     import torch
 
     from pcl_tracking_amd import build as _hip_build
     from pcl_tracking_amd import scene
 
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1:
-        try:  # no-op when pcl_tracking_amd/_build/libpft_hip.so is current (it ships with the snapshot); multi-rank
-            _hip_build.build()  # launches rely on the shipped library (no rebuild under the other ranks' feet)
-        except Exception as e:  # a shipped library is still usable if the rebuild is not possible here
-            sys.stderr.write("bench: rebuild skipped (%s)\n" % e)
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if ARGS.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (ARGS.gpus, world))
+    if world == 1:
+        try:  # no-op when pcl_tracking_amd/_build/libpft_hip.so is current (it ships with the snapshot); multi-rank
+            _hip_build.build()  # launches rely on the library their parent / the snapshot provides
+        except Exception as e:  # a shipped library is still usable if the rebuild is not possible here
+            sys.stderr.write("bench: rebuild skipped (%s)\n" % e)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: LOCAL_RANK %d but %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     force_dist = os.environ.get("PFT_DIST_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ  # 1-rank rehearsal
-    if world > 1 or force_dist:
+    use_dist = world > 1 or force_dist
+    if use_dist:
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=dev)
 
     P_local = ARGS.particles_per_gpu
-    P_total = P_local * world
+    sharded = world > 1 and ARGS.objects == 1  # several objects are replicas (one handle each), never sharded
+    P_total = P_local * world if sharded else P_local
     M, N = ARGS.model_points, ARGS.cloud_points
-    model = scene.make_model(M)
     cloud = scene.make_scene(N, mode="organized" if ARGS.organized else "voxel")
     trans = scene.initial_trans()
     cloud_dev = torch.from_numpy(cloud.view(np.uint8).reshape(-1).copy()).to(dev)  # PCL 32-B layout in HBM
 
     def sync():
-        if world > 1 or force_dist:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world == 1 and not force_dist:
+    my_objects = 1
+    if ARGS.objects > 1 or not use_dist:
         from pcl_tracking_amd import tracker
 
-        # independent objects are independent handles, each on its own HIP stream (the reference tracks them in
-        # a sequential loop, auto_tracking.cpp:688-697)
+        # independent objects are independent handles, each on its own HIP stream (the reference tracks them in a
+        # sequential loop, auto_tracking.cpp:688-697); with several ranks the objects are dealt out round-robin
+        # ("replicas only": no data-path collective)
         ts = []
         for k in range(ARGS.objects):
-            t = tracker.make_reference_tracker(particle_num=P_total, seed=1 + k, device_id=local_rank)
-            t.setReferenceCloud(model)
+            if k % world != rank:
+                continue
+            t = tracker.make_reference_tracker(particle_num=P_local, seed=1 + k, device_id=local_rank)
+            # one model cloud per object (BASELINE configs[4]: "4 independent model clouds")
+            t.setReferenceCloud(scene.make_model(M) if k == 0 else scene.make_model(M, seed=scene.MODEL_SEED + k))
             t.setTrans(trans)
             ts.append(t)
+        my_objects = len(ts)
+        model = scene.make_model(M)
 
-        def step():
+        def run_frame(restore):
             for t in ts:
+                if restore:
+                    t.debugStateRestore()
                 t.setInputCloudDevice(cloud_dev.data_ptr(), N, keepalive=cloud_dev)
                 t.compute()
 
-        trk = ts[0]
+        def save_state():
+            for t in ts:
+                t.debugStateSave()
+
+        trk = ts[0] if ts else None
     else:
         from pcl_tracking_amd.dist import HipPhases, ShardedFilter
 
+        model = scene.make_model(M)
         ph = HipPhases(P_total, rank, world, dev, seed=1)
         ph.set_reference(model)
         ph.set_trans(trans)
         sf = ShardedFilter(ph)
 
-        def step():
+        def run_frame(restore):
+            if restore:
+                ph.t.debugStateRestore()
             ph.set_input_device(cloud_dev, N)
             sf.compute()
+
+        def save_state():
+            ph.t.debugStateSave()
 
         trk = ph.t
 
     sync()
     tc = time.perf_counter()
-    step()  # cold: buffer growth, initParticles, first octree
+    run_frame(False)  # cold: buffer growth, initParticles, first octree
     sync()
     cold_ms = (time.perf_counter() - tc) * 1e3
     for _ in range(ARGS.warmup):
-        step()
+        run_frame(False)
     sync()
-    t0 = time.perf_counter()
-    for _ in range(ARGS.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
-    ms_per_step = dt / ARGS.steps * 1e3
+    save_state()  # the frame every timed step replays: frame `warmup + 2` of the run
 
-    # ---- per-kernel durations: HIP events on the kernels' own stream, same loop again ----
-    trk.profileEnable(True)
-    trk.profileReset()
+    def timed(restore):
+        for _ in range(3):
+            run_frame(restore)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(ARGS.steps):
+            run_frame(restore)
+        sync()
+        dt = time.perf_counter() - t0
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    replay = not ARGS.running
+    dt = timed(replay)
+    ms_per_step = dt / ARGS.steps * 1e3
+    dt_other = timed(not replay)  # the other mode, reported beside the headline
+
+    # ranks that actually took part (never a constant: a launch that lost ranks must not report them)
+    took_part = torch.ones(1, dtype=torch.int32, device=dev)
+    if world > 1:
+        dist.all_reduce(took_part)
+    n_ranks = int(took_part.item())
+    if n_ranks != ARGS.gpus:
+        raise SystemExit("bench.py: %d rank(s) took part but --gpus %d" % (n_ranks, ARGS.gpus))
+
+    # ---- per-kernel durations: HIP events on the kernels' own stream, the headline loop again ----
+    prof, lik_ms, lik_n, dt_prof = {}, 0.0, 0, 0.0
+    if trk is not None:
+        trk.profileEnable(True)
+        trk.profileReset()
     sync()
     t1 = time.perf_counter()
     for _ in range(ARGS.steps):
-        step()
+        run_frame(replay)
     sync()
     dt_prof = time.perf_counter() - t1
-    prof = trk.profileGet()
-    trk.profileEnable(False)
-    lik_ms, lik_n = prof["likelihood"]
+    if trk is not None:
+        prof = trk.profileGet()
+        trk.profileEnable(False)
+        lik_ms, lik_n = prof["likelihood"]
     lik_avg_s = lik_ms / max(1, lik_n) * 1e-3
 
     out = None
     if rank == 0:
-        # mean leaf occupancy of the steady-state workload (counted on the device, outside the timed region)
-        pcur = trk.getParticles()[:P_local]
-        st = trk.evalWeights(pcur, want_nn=True)
+        # mean leaf occupancy of the replayed frame's second likelihood launch (counted on the device, outside the
+        # timed region): the particles after a replayed step are exactly the ones that launch evaluated
+        if replay:
+            run_frame(True)
+        pcur = trk.getParticles()
+        if sharded:
+            pcur = pcur[rank * P_local:(rank + 1) * P_local]
+        st = trk.evalWeights(pcur[:P_local], want_nn=True)
         kbar = st["scan_points"] / max(1, st["scan_queries"])
         # algorithmic bytes: per pair-eval 16 B reference point + 16 B per candidate scanned
         bytes_per_launch = P_local * M * 16.0 * (1.0 + kbar)
         achieved = bytes_per_launch / lik_avg_s / 1e9 if lik_avg_s > 0 else 0.0
-        traffic = None
+        key = "P%d_M%d_N%d%s" % (P_local, M, N, "_organized" if ARGS.organized else "")
+        pmc = {}
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
-                tj = json.load(open(tf))
-                key = "P%d_M%d_N%d" % (P_local, M, N)
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                pmc = json.load(open(tf)).get(key, {})
             except Exception:
-                traffic = None
-        pips = ARGS.objects * P_total * N / (dt / ARGS.steps)
+                pmc = {}
+        traffic = pmc.get("hbm_bytes_per_launch")
+        n_obj = ARGS.objects
+        pips = n_obj * P_total * N / (dt / ARGS.steps)
+        iters = 2
+        frame_bytes = iters * bytes_per_launch * (world if sharded else 1) * n_obj  # B_frame = I P M 16 (1 + k)
+        frame_gbs = frame_bytes / (dt / ARGS.steps) / 1e9
         out = {
             "metric": "particles x input-points / sec per frame (tracked frames/sec @8192 particles per GPU)",
             "value": pips,
             "unit": "particle-points/s",
-            "n_gpus": world,
+            "n_gpus": n_ranks,
             "steps": ARGS.steps,
             "warmup": ARGS.warmup,
             "ms_per_step": ms_per_step,
@@ -279,14 +402,18 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: %d-pt model vs %d-pt %s cloud, %d particles/GPU, 2 iterations/frame, "
-                            "single frame looped" % (M, N, "organized" if ARGS.organized else "voxel-downsampled", P_local),
-                "particles_total": P_total, "model_points": M, "cloud_points": N, "iterations_per_frame": 2,
-                "parallelism": "particles sharded x%d" % world, "objects": ARGS.objects,
+                "workload": workload_label(P_local, M, N, ARGS.organized, n_obj, world),
+                "mode": "replayed frame (state checkpointed after the warm-up, restored before every step)" if replay
+                        else "free-running filter",
+                "particles_total": P_total, "model_points": M, "cloud_points": N, "iterations_per_frame": iters,
+                "parallelism": ("particles sharded x%d (RCCL world size %d)" % (world, world)) if sharded else
+                               ("%d object replica(s) over %d rank(s), no collective" % (n_obj, world)),
+                "objects": n_obj,
             },
             "frames_per_s": ARGS.steps / dt,
             "cold_first_frame_ms": cold_ms,
-            "pair_evals_per_s": 2.0 * P_total * M / (dt / ARGS.steps),
+            ("ms_per_step_running" if replay else "ms_per_step_replayed"): dt_other / ARGS.steps * 1e3,
+            "pair_evals_per_s": float(iters) * n_obj * P_total * M / (dt / ARGS.steps),
             "cropped_points": int(len(st["crop_idx"])), "octree_depth": int(st["octree_depth"]),
             "mean_leaf_occupancy": kbar,
             "ms_per_step_with_events": dt_prof / ARGS.steps * 1e3,
@@ -296,44 +423,51 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": lik_avg_s * 1e6,
                 "launches": int(lik_n),
+                "note": "algorithmic bytes (SURVEY 8d) over the live launch time; the working set is LDS / L2-resident "
+                        "(see traffic), so HBM is the yardstick BASELINE.json asks for, not the limiter: roofline_valu",
             },
+            # the whole frame against the same roof (B_frame / t_compute): what the tracked-frames rate is worth
+            "roofline_frame": {"bound": "hbm", "achieved": frame_gbs, "peak": HBM_PEAK_GBS * n_ranks, "unit": "GB/s",
+                               "frac": frame_gbs / (HBM_PEAK_GBS * n_ranks), "algorithmic_bytes_per_frame": frame_bytes},
         }
-        if P_local == P_PER_GPU and M == M_MODEL and N == N_CLOUD and not ARGS.organized:
-            # interpretation aid (SURVEY 8d "secondary (VALU) roof"): the kernel's working set is LDS/L2-resident and it
-            # is VALU-issue bound.  Instruction count per launch from the committed PMC pass of this very workload
-            # (profiles/r01_pmc_sq_counters.txt: SQ_INSTS_VALU of k_likelihood<false>); the duration is the live one.
-            valu_insts = 1.572e8
-            # Measured on this part (tools/micro/valu_rate_test.hip): a wave64 VALU instruction occupies its SIMD for
-            # 2.5-2.7 cycles if it is a plain add / sub / mul / and / or, 4.1-4.4 cycles otherwise (compares, selects,
-            # shifts, bit-field, fused and three-operand forms: two thirds of this kernel's child selection).  The
-            # figure below is the SIMD time the launch spends per instruction: between those two costs = the VALU
-            # pipes are busy for essentially the whole launch.
-            out["roofline"]["valu_issue"] = {
-                "wave_insts_per_launch": valu_insts, "wave_insts_per_s": valu_insts / lik_avg_s,
-                "simd_cycles_per_wave_inst": lik_avg_s * 2.4e9 * 256 * 4 / valu_insts,
-                "measured_cost_cycles": {"add_sub_mul_and_or": 2.5, "compare_select_shift_bitfield_fma": 4.2},
-                "source": "profiles/r01_pmc_sq_counters.txt (SQ_INSTS_VALU of this workload); duration measured live"}
-        if world == 1 and not ARGS.no_cpu_baseline:
+        if pmc.get("valu_wave_insts_per_launch"):
+            # what actually limits k_likelihood: VALU issue.  Instruction and lane-cycle counts per launch from the
+            # committed PMC pass of this workload (profiles/, tools/pmc.sh); the duration is the live one; the peak is
+            # the guide's 2 cycles per wave64 VALU instruction on each of the 1024 SIMD-32s at 2.4 GHz.
+            vi = float(pmc["valu_wave_insts_per_launch"])
+            out["roofline_valu"] = {
+                "bound": "valu_issue", "kernel": "k_likelihood", "achieved": vi / lik_avg_s, "peak": VALU_ISSUE_PEAK,
+                "unit": "wave-inst/s", "frac": vi / lik_avg_s / VALU_ISSUE_PEAK,
+                "lane_util": pmc.get("valu_lane_utilisation"),
+                "wave_insts_per_launch": vi, "valu_insts_per_wave_query_round": vi / (P_local * M / 64.0),
+                "source": pmc.get("source"),
+            }
+        if world == 1 and n_obj == 1 and not ARGS.no_cpu_baseline:
             cores = os.cpu_count() or 1
-            tmin, tmed, stages = cpu_baseline(model, cloud, trans, P_total, cores)
+            tmin, tmed, stages, nfr = cpu_baseline(model, cloud, trans, P_total, cores, frames=ARGS.cpu_frames,
+                                                   seconds=ARGS.cpu_seconds)
             out["cpu_baseline"] = {
-                "value": P_total * N / tmin, "unit": "particle-points/s", "cores": cores, "kind": "port",
-                "sample": "%d frames of the same workload (P=%d, M=%d, N=%d, 2 iterations) after 1 warm-up frame; "
-                          "min frame time %.3f s, median %.3f s" % (ARGS.cpu_frames, P_total, M, N, tmin, tmed),
+                "value": P_total * N / tmed, "unit": "particle-points/s", "cores": cores, "kind": "port",
+                "sample": "%d timed frames of the same workload (P=%d, M=%d, N=%d, 2 iterations; free-running filter) after "
+                          "3 warm-up frames, bounded at %.0f s of timed work; median frame time %.3f s (value), min %.3f s"
+                          % (nfr, P_total, M, N, ARGS.cpu_seconds, tmed, tmin),
+                "frames": nfr, "median_s": tmed, "min_s": tmin,
                 "stage_seconds": {k: round(float(v), 4) for k, v in zip(
                     ("transform", "bbox_crop", "octree", "coherence", "normalize", "resample", "update"), stages)},
             }
             out["speedup_vs_cpu"] = pips / out["cpu_baseline"]["value"]
             # the same port without PCL's per-query index-vector allocation ("optimised CPU"): so that
             # the ratio is not credited to de-pessimising the allocator behaviour alone
-            fmin, fmed, _ = cpu_baseline(model, cloud, trans, P_total, cores, pcl_alloc=0)
-            out["cpu_optimised"] = {"value": P_total * N / fmin, "unit": "particle-points/s", "cores": cores,
-                                    "kind": "port", "sample": "same, emulate_pcl_alloc=0; min frame time %.3f s" % fmin}
+            fmin, fmed, _, nf2 = cpu_baseline(model, cloud, trans, P_total, cores, pcl_alloc=0, frames=5,
+                                              seconds=ARGS.cpu_seconds / 3, warm=1)
+            out["cpu_optimised"] = {"value": P_total * N / fmed, "unit": "particle-points/s", "cores": cores,
+                                    "kind": "port", "sample": "same, emulate_pcl_alloc=0; %d frames, median %.3f s, min %.3f s"
+                                                              % (nf2, fmed, fmin)}
             out["speedup_vs_cpu_optimised"] = pips / out["cpu_optimised"]["value"]
-        if world == 1 and not ARGS.no_frontend:
+        if world == 1 and n_obj == 1 and not ARGS.no_frontend:
             out["frontend"] = frontend_measurement(dev, not ARGS.no_cpu_baseline)
             out["reference_operating_point"] = reference_operating_point(model, cloud, trans, dev, not ARGS.no_cpu_baseline)
-    if world > 1 or force_dist:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PFT_ABI_VERSION 3
+#define PFT_ABI_VERSION 4
 
 /* pcl::PointXYZRGBA (32 B, 16-aligned): x,y,z,1.0f | rgba (bytes b,g,r,a) | 12 B pad */
 typedef struct pft_point_xyzrgba {
@@ -114,7 +114,13 @@ int pft_set_input_device(pft_tracker* t, const void* device_pts, size_t n);
 /* tracker_->compute() :693 -- first call runs initParticles; then iteration_num x
  * [resample, weight, update].  Asynchronous on the handle's stream. */
 int pft_compute(pft_tracker* t);
-/* tracker_->getResult() :309 -- synchronises the stream */
+/* tracker_->getResult() :309 -- synchronises the stream.  Like every call that synchronises (pft_get_particles,
+ * pft_get_fit_ratio, pft_synchronize, pft_eval_weights) it also reports device-side failures of the iterations run
+ * since the last such call: PFT_ERR_CAPACITY (octree node capacity, depth or bounding-box growth steps exceeded) or
+ * PFT_ERR_HIP (the one-pass crop gave up waiting), pft_last_error_string naming the flag.  The affected iteration ran
+ * without a target cloud (all likelihoods zero), so the pose returned with the error is the unweighted particle mean;
+ * the flags are per iteration and the next pft_compute starts clean.  (PCL's compute() is void; the reference's caller
+ * wraps it in try / catch, auto_tracking.cpp:692-696.) */
 int pft_get_result(pft_tracker* t, pft_particle* out);
 /* tracker_->getParticles() :270 -- copy-out of all particle_num particles (all ranks' shards) */
 int pft_get_particles(pft_tracker* t, pft_particle* out, size_t cap, size_t* n);
@@ -151,6 +157,18 @@ int pft_debug_get_octree(pft_tracker* t, int32_t* depth, double min_xyz[3], doub
                          uint32_t* n_nodes);
 int pft_debug_get_point_keys(pft_tracker* t, uint32_t* keys3, size_t cap_points);
 int pft_debug_get_scan_stats(pft_tracker* t, uint64_t* queries, uint64_t* scanned_points);
+/* limits for the error-path tests: max_words != 0 lowers the octree node capacity (never above the allocation),
+ * sorted_npass != 0 fixes the radix passes of the sorted builder (0 = derived from the previous depth) */
+int pft_debug_set_limits(pft_tracker* t, uint32_t max_words, int sorted_npass);
+/* checkpoint of the filter state between two frames (population with weights, alias table, representative state,
+ * motion, KLD particle count, resample epoch); restore is one kernel on the handle's stream.  bench.py replays the
+ * same frame with it (stationary workload); tests use it to compare two schedules from the same state. */
+int pft_debug_state_save(pft_tracker* t);
+int pft_debug_state_restore(pft_tracker* t);
+/* OR `bits` into the device-side error flags right after the next crop launch (what a failing stage leaves behind) */
+int pft_debug_inject_error(pft_tracker* t, uint32_t bits);
+/* the pinned status block: [0] last crop size, [1] last depth, [2] flags of the last failed iteration, [3] unreported flags */
+int pft_debug_get_host_stat(pft_tracker* t, uint32_t out4[4]);
 /* wall-clock stamps (100 MHz ticks) taken at phase boundaries inside the single-workgroup kernels of the
  * last iteration: [0..15] octree build, [16..31] population */
 int pft_debug_get_ticks(pft_tracker* t, uint64_t* ticks32);

@@ -106,6 +106,7 @@ def lib():
     L.orc_tracker_set_matrix_override.argtypes = [vp, vp]
     L.orc_tracker_set_bbox_override.argtypes = [vp, vp]
     L.orc_tracker_set_bbox_only.argtypes = [vp, C.c_int]
+    L.orc_tracker_set_trig_mode.argtypes = [vp, C.c_int]
     L.orc_kld_normal_quantile.argtypes = [f64]
     L.orc_kld_normal_quantile.restype = f64
     L.orc_kld_bound.argtypes = [C.c_int, f64, f64]
@@ -373,6 +374,11 @@ class Tracker:
 
     def fit_ratio(self):
         return lib().orc_tracker_fit_ratio(self.h)
+
+    def set_trig_mode(self, mode):
+        """tests only: 0 = A1 with cosf / sinf as PCL (default); 1 = double sin / cos rounded to float, as the
+        product's device code forms the matrix (identical matrices on both sides: bit-level long-run comparison)"""
+        lib().orc_tracker_set_trig_mode(self.h, int(mode))
 
     def stage_times(self):
         s = np.zeros(7, np.float64)

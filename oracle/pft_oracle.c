@@ -70,6 +70,21 @@ void orc_get_transformation(float x, float y, float z, float roll, float pitch, 
   m[12] = 0;     m[13] = 0;              m[14] = 0;              m[15] = 1;
 }
 
+/* TEST-ONLY variant of A1 (orc_tracker_set_trig_mode(t, 1)): sin / cos evaluated in double and rounded to float,
+ * which is how the product's device code forms the matrix (DESIGN.md "numerics").  PCL itself calls cosf / sinf
+ * (above, the default); the two agree to <= 1 ulp(float) per trig value.  With this variant the oracle and the
+ * device see identical matrices, so whole tracking runs can be compared bit for bit over many frames
+ * (tests/test_gpu_longrun.py); the default-mode comparison stays in place beside it. */
+static void get_transformation_double_trig(float x, float y, float z, float roll, float pitch, float yaw, float m[16]) {
+  float A = (float)cos((double)yaw), B = (float)sin((double)yaw), C = (float)cos((double)pitch),
+        D = (float)sin((double)pitch);
+  float E = (float)cos((double)roll), F = (float)sin((double)roll), DE = D * E, DF = D * F;
+  m[0] = A * C;  m[1] = A * DF - B * E;  m[2] = B * F + A * DE;  m[3] = x;
+  m[4] = B * C;  m[5] = A * E + B * DF;  m[6] = B * DE - A * F;  m[7] = y;
+  m[8] = -D;     m[9] = C * F;           m[10] = C * E;          m[11] = z;
+  m[12] = 0;     m[13] = 0;              m[14] = 0;              m[15] = 1;
+}
+
 /* A0  ParticleXYZRPY::toState -> pcl::getTranslationAndEulerAngles (same file) */
 void orc_to_state(const float m[16], orc_particle_t* out) {
   memset(out, 0, sizeof(*out));
@@ -731,6 +746,7 @@ struct orc_tracker {
   const float* mat_override; /* tests: P row-major 4x4 matrices used instead of toEigenMatrix(p) */
   const double* bbox_override; /* tests: x_min,x_max,y_min,y_max,z_min,z_max used instead of calcBoundingBox */
   int bbox_only;               /* tests: stop after calcBoundingBox */
+  int trig_mode;               /* tests: 0 = cosf / sinf as PCL (default), 1 = double sin / cos rounded to float */
 };
 
 orc_tracker_t* orc_tracker_create(const orc_config_t* c) {
@@ -739,6 +755,8 @@ orc_tracker_t* orc_tracker_create(const orc_config_t* c) {
   for (int i = 0; i < 16; i++) t->trans[i] = (i % 5 == 0) ? 1.0f : 0.0f;
   return t;
 }
+
+void orc_tracker_set_trig_mode(orc_tracker_t* t, int mode) { t->trig_mode = mode; }
 
 void orc_tracker_destroy(orc_tracker_t* t) {
   if (!t) return;
@@ -837,6 +855,8 @@ size_t orc_tracker_eval_weights(orc_tracker_t* t, const orc_particle_t* particle
     const orc_particle_t* p = &particles[i];
     if (t->mat_override)
       memcpy(T, t->mat_override + 16 * (size_t)i, sizeof(T));
+    else if (t->trig_mode == 1)
+      get_transformation_double_trig(p->x, p->y, p->z, p->roll, p->pitch, p->yaw, T);
     else
       orc_get_transformation(p->x, p->y, p->z, p->roll, p->pitch, p->yaw, T);
     orc_transform_cloud(t->ref, M, T, t->transed + (size_t)i * M);

@@ -136,6 +136,9 @@ double orc_tracker_fit_ratio(const orc_tracker_t* t);
 /* tests only: use these P row-major 4x4 matrices instead of toEigenMatrix(particle) in eval_weights
  * (isolates the float descent/coherence arithmetic from libm-vs-ocml sin/cos ulp differences) */
 void orc_tracker_set_matrix_override(orc_tracker_t* t, const float* m16);
+/* tests only: 0 (default) = A1 with cosf / sinf as PCL; 1 = sin / cos in double rounded to float, the way the product's
+ * device code forms the matrix -- identical matrices on both sides, for bit-level comparison of long tracking runs */
+void orc_tracker_set_trig_mode(orc_tracker_t* t, int mode);
 /* tests of the particle-sharded host logic: crop with this box (the reduction over all ranks) instead of
  * the box of the given particles; bbox_only stops eval_weights after calcBoundingBox */
 void orc_tracker_set_bbox_override(orc_tracker_t* t, const double* bbox6);

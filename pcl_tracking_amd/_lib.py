@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libpft_hip.so")
 
-PFT_ABI_VERSION = 3
+PFT_ABI_VERSION = 4
 K_RESAMPLE, K_AABB, K_CROP, K_OCTREE, K_LIKELIHOOD, K_POPULATION, K_PACK, K_COUNT = range(8)
 
 STATUS = {0: "ok", 1: "invalid argument", 2: "no input cloud", 3: "no reference cloud", 4: "no usable HIP device",
@@ -84,6 +84,11 @@ SYMBOLS = [
     ("pft_debug_get_octree", C.c_int, [_vp, _P(_i32), _vp, _vp, _P(_u32), _P(_u32)]),
     ("pft_debug_get_point_keys", C.c_int, [_vp, _vp, _sz]),
     ("pft_debug_get_scan_stats", C.c_int, [_vp, _P(_u64), _P(_u64)]),
+    ("pft_debug_set_limits", C.c_int, [_vp, _u32, C.c_int]),
+    ("pft_debug_inject_error", C.c_int, [_vp, _u32]),
+    ("pft_debug_state_save", C.c_int, [_vp]),
+    ("pft_debug_state_restore", C.c_int, [_vp]),
+    ("pft_debug_get_host_stat", C.c_int, [_vp, _vp]),
     ("pft_debug_get_ticks", C.c_int, [_vp, _vp]),
     ("pft_debug_get_descent_stats", C.c_int, [_vp, _vp]),
     ("pft_debug_set_ablate", None, [C.c_int]),

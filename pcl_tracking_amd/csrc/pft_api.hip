@@ -64,6 +64,8 @@ struct pft_tracker {
   SortBufs sort = {};
   uint32_t* h_stat = nullptr;   // pinned, device-visible
   int force_builder = 0;        // PFT_FORCE_BUILDER: 1 single workgroup, 2 sorted
+  int force_npass = 0;          // test hook (pft_debug_set_limits): radix passes of the sorted builder, 0 = from the last depth
+  uint32_t inject_error = 0;    // test hook (pft_debug_inject_error): bits OR-ed into PftHeader::error after the next crop
   double* d_partial = nullptr;
   int32_t* d_alias_list = nullptr;
   double* d_alias_pref = nullptr;
@@ -89,6 +91,16 @@ struct pft_tracker {
   size_t dbg_f_cap = 0;
   // dist binding
   void *bound_bbox6 = nullptr, *bound_shard = nullptr, *bound_gathered = nullptr;
+
+  // pft_debug_state_save / _restore: a checkpoint of the filter state in HBM (bench.py's stationary workload, tests)
+  pft_particle* sv_part = nullptr;
+  int32_t* sv_alias_list = nullptr;
+  double* sv_alias_pref = nullptr;
+  uint32_t* sv_alias_pos = nullptr;
+  PftHeader* sv_hdr = nullptr;
+  int sv_cur = 0;
+  uint32_t sv_epoch = 0;
+  bool sv_changed = false, sv_valid = false;
 
   // state
   bool has_ref = false, has_input = false, initialized = false, changed = false;
@@ -339,6 +351,26 @@ static void sync_dev(pft_tracker* t) {
   d.nn_d2 = t->d_nn_d2;
 }
 
+// Device-side failures (PftHeader::error: octree capacity, depth / growth overflow, the one-pass crop's bounded wait)
+// make the likelihood launch of that iteration run without a target -- all weights zero, the update degenerates to
+// the unweighted mean.  The likelihood kernel mirrors the flags into pinned host memory; every host synchronisation
+// point calls this AFTER the stream has drained and hands the failure to the caller (the reference's caller looks for
+// one: auto_tracking.cpp:692-696).  The flags are per iteration, so the next compute() starts clean.
+static int check_device_error(pft_tracker* t) {
+  volatile uint32_t* hs = t->h_stat;
+  const uint32_t e = hs ? hs[3] : 0u;
+  if (!e) return PFT_OK;
+  hs[3] = 0u;
+  std::string m = "device error flag(s) raised since the last check:";
+  if (e & 1u) m += " [bit0] octree node capacity exceeded (more than 8 x input points + 64 words, or 2^24 nodes);";
+  if (e & 2u) m += " [bit1] octree depth / bounding-box growth steps exceeded (PFT_MAX_DEPTH 30, PFT_MAX_GROW 40);";
+  if (e & 4u) m += " [bit2] the one-pass crop gave up waiting for a predecessor workgroup;";
+  if (e & ~7u) m += " [other] " + std::to_string(e & ~7u) + ";";
+  m += " the affected iteration(s) ran without a target cloud (all likelihoods zero)";
+  t->err = m;
+  return (e & 4u) ? PFT_ERR_HIP : PFT_ERR_CAPACITY;
+}
+
 static int ensure_input_capacity(pft_tracker* t, uint32_t n) {
   if (n <= t->in_cap) return PFT_OK;
   if ((uint64_t)n * 8ull + 64ull >= (1ull << 24)) {
@@ -346,6 +378,7 @@ static int ensure_input_capacity(pft_tracker* t, uint32_t n) {
     return PFT_ERR_CAPACITY;
   }
   hipStreamSynchronize(t->stream);
+  t->in_cap = 0;  // a failing allocation below leaves null buffers: they must not look usable
   dfree(t->d_in_raw); dfree(t->d_in_pts); dfree(t->d_crop_counts); dfree(t->d_crop_slots); dfree(t->d_crop_pts); dfree(t->d_crop_idx);
   dfree(t->d_words); dfree(t->d_leaf_pts); dfree(t->d_leaf_order); dfree(t->d_pt_node); dfree(t->d_pt_key);
   dfree(t->d_pt_tmp); dfree(t->d_pt_key64);
@@ -478,7 +511,7 @@ extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
     A(dalloc(&t->d_kld_bins, (size_t)6 * p.kld_max));
   }
   A(hipHostMalloc(reinterpret_cast<void**>(&t->h_stat), 4 * sizeof(uint32_t), hipHostMallocMapped));
-  if (t->h_stat) t->h_stat[0] = t->h_stat[1] = 0;
+  if (t->h_stat) t->h_stat[0] = t->h_stat[1] = t->h_stat[2] = t->h_stat[3] = 0;
   {
     const char* fb = getenv("PFT_FORCE_BUILDER");
     t->force_builder = fb ? (!strcmp(fb, "single") ? 1 : (!strcmp(fb, "sorted") ? 2 : 0)) : 0;
@@ -525,6 +558,7 @@ extern "C" void pft_destroy(pft_tracker* t) {
   dfree(t->d_partial); dfree(t->d_alias_list); dfree(t->d_alias_pos); dfree(t->d_raw_w);
   dfree(t->d_alias_pref); dfree(t->d_pop_part); dfree(t->d_kld_table); dfree(t->d_kld_bins); dfree(t->d_eg_start); dfree(t->d_eg_cnt); dfree(t->d_eg_tile); dfree(t->d_ec_slot); dfree(t->d_ec_cells); dfree(t->d_ec_count); dfree(t->d_ec_base); dfree(t->d_ec_list); dfree(t->d_hdr); dfree(t->d_nn_idx); dfree(t->d_nn_d2); dfree(t->d_dbg_part);
   dfree(t->d_dbg_hdr); dfree(t->d_dbg_f);
+  dfree(t->sv_part); dfree(t->sv_alias_list); dfree(t->sv_alias_pref); dfree(t->sv_alias_pos); dfree(t->sv_hdr);
   if (t->own_stream && t->stream) hipStreamDestroy(t->stream);
   delete t;
 }
@@ -534,7 +568,7 @@ extern "C" const char* pft_last_error_string(const pft_tracker* t) { return t ? 
 extern "C" int pft_synchronize(pft_tracker* t) {
   if (!t) return PFT_ERR_INVALID_ARG;
   HIPCHK(t, hipStreamSynchronize(t->stream));
-  return PFT_OK;
+  return check_device_error(t);
 }
 
 extern "C" int pft_set_reference(pft_tracker* t, const pft_point_xyzrgba* pts, size_t n) {
@@ -620,6 +654,7 @@ extern "C" int pft_set_reference(pft_tracker* t, const pft_point_xyzrgba* pts, s
     HIPCHK(t, hipStreamSynchronize(t->stream));
   }
   t->has_ref = true;
+  if (t->h_stat) t->h_stat[0] = t->h_stat[1] = 0;  // new scene: forget the builder hints (unknown depth = all radix passes)
   sync_dev(t);
   return PFT_OK;
 }
@@ -695,12 +730,18 @@ static void stage_aabb(pft_tracker* t, const PftDev& d, uint32_t np, bool finali
   pftk_aabb(t->stream, t->prm, d, np, finalize);
 }
 // A4, A5, A6+A7
+__global__ void k_inject_error(PftHeader* hdr, uint32_t bits) { hdr->error |= bits; }
+
 static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32_t np, bool debug_nn,
                                          bool bbox_from_partials, bool keep_point_keys = false) {
   {
     ProfScope ps(t, PFT_K_CROP);
     if (++t->crop_epoch == 0) t->crop_epoch = 1;
     pftk_crop(t->stream, t->prm, d, bbox_from_partials, t->crop_epoch);
+    if (t->inject_error) {  // test hook: what a failing crop / builder would leave behind
+      hipLaunchKernelGGL(k_inject_error, dim3(1), dim3(1), 0, t->stream, t->d_hdr, t->inject_error);
+      t->inject_error = 0;
+    }
   }
   if (t->cfg.exact_nearest) {  // NearestPairPointCloudCoherence: uniform grid + true nearest neighbour, no octree
     {
@@ -730,7 +771,10 @@ static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32
     } else if (sorted) {
       // 8-bit passes for 3 bits per level; one level of head-room over the last depth (k_so_scan flags an error
       // if the tree turned out deeper than the passes cover)
+      // (a deeper tree than the passes cover is rebuilt by the rescue launch behind the sorted builder: the guess
+      // costs time when it is wrong, never the iteration)
       int npass = last_depth > 0u ? (int)((3u * (last_depth + 1u) + 7u) / 8u) : 8;
+      if (t->force_npass > 0) npass = t->force_npass;
       if (npass > 8) npass = 8;
       pftk_octree_sorted(t->stream, t->prm, db, t->sort, d.N, npass);
     }
@@ -853,14 +897,14 @@ extern "C" int pft_get_result(pft_tracker* t, pft_particle* out) {
   if (!t || !out) return PFT_ERR_INVALID_ARG;
   HIPCHK(t, hipMemcpyAsync(out, &t->d_hdr->rep, sizeof(pft_particle), hipMemcpyDeviceToHost, t->stream));
   HIPCHK(t, hipStreamSynchronize(t->stream));
-  return PFT_OK;
+  return check_device_error(t);  // the pose is written either way; a failed iteration makes it the unweighted mean
 }
 
 extern "C" int pft_get_fit_ratio(pft_tracker* t, double* out) {
   if (!t || !out) return PFT_ERR_INVALID_ARG;
   HIPCHK(t, hipMemcpyAsync(out, &t->d_hdr->fit_ratio, sizeof(double), hipMemcpyDeviceToHost, t->stream));
   HIPCHK(t, hipStreamSynchronize(t->stream));
-  return PFT_OK;
+  return check_device_error(t);
 }
 
 extern "C" int pft_get_particles(pft_tracker* t, pft_particle* out, size_t cap, size_t* n) {
@@ -879,7 +923,7 @@ extern "C" int pft_get_particles(pft_tracker* t, pft_particle* out, size_t cap, 
   sync_dev(t);
   HIPCHK(t, hipMemcpyAsync(out, t->dev.part_all, c * sizeof(pft_particle), hipMemcpyDeviceToHost, t->stream));
   HIPCHK(t, hipStreamSynchronize(t->stream));
-  return PFT_OK;
+  return check_device_error(t);
 }
 
 extern "C" int pft_set_particles(pft_tracker* t, const pft_particle* p, size_t n) {
@@ -899,10 +943,104 @@ extern "C" int pft_set_particles(pft_tracker* t, const pft_particle* p, size_t n
   HIPCHK(t, hipStreamSynchronize(t->stream));
   t->initialized = true;
   t->changed = false;
+  if (t->h_stat) t->h_stat[0] = t->h_stat[1] = 0;  // the spread of the particles decides the crop: forget the builder hints
   return PFT_OK;
 }
 
 // ---- test hooks ----
+extern "C" int pft_debug_set_limits(pft_tracker* t, uint32_t max_words, int sorted_npass) {
+  if (!t) return PFT_ERR_INVALID_ARG;
+  hipStreamSynchronize(t->stream);
+  if (max_words) {
+    if (t->in_cap == 0 || max_words > t->in_cap * 8u + 64u) return PFT_ERR_CAPACITY;  // only ever below the allocation
+    t->max_words = max_words;
+  }
+  t->force_npass = sorted_npass;
+  sync_dev(t);
+  return PFT_OK;
+}
+// ---- checkpoint of the filter state (between frames): the whole population with its weights, the alias prefix form the
+// next resample draws from, the header (representative state, motion, KLD particle count) and the host-side schedule
+// state.  Restoring is ONE kernel on the handle's stream, so a benchmark can replay the same frame again and again.
+struct CopySeg {
+  const uint32_t* src;
+  uint32_t* dst;
+  uint32_t n;  // 32-bit words
+};
+struct CopySegs {
+  CopySeg s[5];
+};
+__global__ __launch_bounds__(256) void k_copy_segments(CopySegs cs) {
+  const CopySeg g = cs.s[blockIdx.y];
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += gridDim.x * blockDim.x) g.dst[i] = g.src[i];
+}
+
+static void state_segments(pft_tracker* t, bool save, CopySegs* cs) {
+  const uint32_t P = t->Pcap;
+  const void* live[5] = {t->dev.part_all, t->d_alias_list, t->d_alias_pref, t->d_alias_pos, t->d_hdr};
+  void* saved[5] = {t->sv_part, t->sv_alias_list, t->sv_alias_pref, t->sv_alias_pos, t->sv_hdr};
+  const uint32_t words[5] = {P * 8u, P * 2u, P * 4u, P, (uint32_t)(sizeof(PftHeader) / 4u)};
+  for (int k = 0; k < 5; k++) {
+    cs->s[k].src = static_cast<const uint32_t*>(save ? live[k] : saved[k]);
+    cs->s[k].dst = static_cast<uint32_t*>(save ? saved[k] : const_cast<void*>(live[k]));
+    cs->s[k].n = words[k];
+  }
+}
+
+extern "C" int pft_debug_state_save(pft_tracker* t) {
+  if (!t) return PFT_ERR_INVALID_ARG;
+  if (!t->initialized) {
+    t->err = "pft_debug_state_save before the first compute";
+    return PFT_ERR_STATE;
+  }
+  hipSetDevice(t->cfg.device_id);
+  if (!t->sv_part) {
+    const size_t P = t->Pcap;
+    HIPCHK(t, dalloc(&t->sv_part, P));
+    HIPCHK(t, dalloc(&t->sv_alias_list, 2 * P));
+    HIPCHK(t, dalloc(&t->sv_alias_pref, 2 * P));
+    HIPCHK(t, dalloc(&t->sv_alias_pos, P));
+    HIPCHK(t, dalloc(&t->sv_hdr, 1));
+  }
+  sync_dev(t);
+  CopySegs cs;
+  state_segments(t, true, &cs);
+  hipLaunchKernelGGL(k_copy_segments, dim3(64, 5), dim3(256), 0, t->stream, cs);
+  HIPCHK(t, hipStreamSynchronize(t->stream));
+  t->sv_cur = t->cur;
+  t->sv_epoch = t->resample_epoch;
+  t->sv_changed = t->changed;
+  t->sv_valid = true;
+  return check_device_error(t);
+}
+
+extern "C" int pft_debug_state_restore(pft_tracker* t) {
+  if (!t) return PFT_ERR_INVALID_ARG;
+  if (!t->sv_valid) {
+    t->err = "pft_debug_state_restore without a saved state";
+    return PFT_ERR_STATE;
+  }
+  hipSetDevice(t->cfg.device_id);
+  t->cur = t->sv_cur;
+  t->resample_epoch = t->sv_epoch;
+  t->changed = t->sv_changed;
+  sync_dev(t);
+  CopySegs cs;
+  state_segments(t, false, &cs);
+  hipLaunchKernelGGL(k_copy_segments, dim3(64, 5), dim3(256), 0, t->stream, cs);
+  return PFT_OK;
+}
+
+extern "C" int pft_debug_inject_error(pft_tracker* t, uint32_t bits) {
+  if (!t) return PFT_ERR_INVALID_ARG;
+  t->inject_error = bits;
+  return PFT_OK;
+}
+extern "C" int pft_debug_get_host_stat(pft_tracker* t, uint32_t out4[4]) {
+  if (!t || !out4 || !t->h_stat) return PFT_ERR_INVALID_ARG;
+  for (int i = 0; i < 4; i++) out4[i] = ((volatile uint32_t*)t->h_stat)[i];
+  return PFT_OK;
+}
 static int ensure_dbg_part(pft_tracker* t, size_t n) {
   if (n > t->dbg_part_cap) {
     hipStreamSynchronize(t->stream);
@@ -961,7 +1099,7 @@ extern "C" int pft_eval_weights(pft_tracker* t, const pft_particle* particles, s
   // the matrices of the live particles were overwritten: restore them
   if (t->initialized) pftk_pose_to_matrix(t->stream, t->d_part[t->cur], t->prm.P_local, t->d_mats);
   HIPCHK(t, hipGetLastError());
-  return PFT_OK;
+  return check_device_error(t);
 }
 
 static int read_hdr(pft_tracker* t, PftHeader* h) {

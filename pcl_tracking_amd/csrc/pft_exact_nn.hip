@@ -25,6 +25,7 @@ __device__ __forceinline__ int eg_cell1(float v, float mn, float inv_g, int dim)
 // grid geometry from the crop box; the cell doubles until the grid fits the cell arrays
 __global__ void k_eg_setup(PftParams prm, PftDev d) {
   PftHeader* h = d.hdr;
+  if (h->error) h->n_crop = 0u;  // a failed crop (bit 2) leaves no target: reported through host_stat by the likelihood kernel
   const uint32_t n = h->n_crop;
   float g = (float)(2.0 * prm.res);
   int dim[3] = {1, 1, 1};
@@ -402,6 +403,10 @@ __global__ __launch_bounds__(256) void k_likelihood_exact(PftParams prm, PftDev 
     lut_s[i] = (float)i / 255.0f;
   }
   __syncthreads();
+  if (h->error && blockIdx.x == 0 && threadIdx.x == 0 && d.host_stat) {  // as k_likelihood: surfaced at the next host sync
+    d.host_stat[2] = h->error;
+    d.host_stat[3] |= h->error;
+  }
   const uint32_t n_crop = h->n_crop;
   const float g = h->eg_g, inv_g = h->eg_inv_g;
   const int dx_ = h->eg_dim[0], dy_ = h->eg_dim[1], dz_ = h->eg_dim[2];

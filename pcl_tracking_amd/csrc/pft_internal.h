@@ -19,6 +19,7 @@
 
 #include "../../include/pft.h"
 
+#define PFT_MAX_DEVICES 64      // per-device caches of one-time kernel attributes
 #define PFT_MAX_DEPTH 30
 #define PFT_TABLE_MAX_DEPTH 10
 #define PFT_MAX_GROW 40
@@ -68,7 +69,9 @@ struct PftParams {  // immutable per handle, passed by value to kernels
 struct PftHeader {  // lives in HBM; written by kernels, read by later kernels (and by the host for debug)
   float bbox[6];    // x_min,x_max,y_min,y_max,z_min,z_max
   uint32_t n_crop;
-  uint32_t error;   // bit0: octree capacity exceeded, bit1: depth / growth steps exceeded
+  uint32_t error;   // per iteration (cleared by the crop kernel): bit0 octree capacity exceeded, bit1 depth / growth steps
+                    // exceeded, bit2 one-pass crop gave up waiting, bit3 (internal, transient) sorted builder's radix passes
+                    // too few -> the rescue launch rebuilds
   double omin[3], omax[3];
   int32_t depth;
   int32_t use_table;
@@ -155,7 +158,9 @@ struct PftDev {  // device pointers (host-side struct, passed by value)
   uint32_t* kld_table;       // KLD variant: open-addressing table of first occurrences, 2 x pow2(kld_max) entries
   int32_t* kld_bins;         // KLD variant: 6 ints per candidate
   uint32_t* host_stat;  // pinned host memory, device-visible: [0] last n_crop, [1] last octree depth (read by the
-                        // host WITHOUT synchronising, to pick the builder for the next iteration)
+                        // host WITHOUT synchronising, to pick the builder for the next iteration: a wrong guess costs
+                        // time, never correctness), [2] error flags of the last failed iteration, [3] error flags
+                        // accumulated since the host last looked (checked and cleared at the host's sync points)
   int32_t* nn_idx;      // debug only
   float* nn_d2;
 };
@@ -183,6 +188,8 @@ void pftk_resample_kld(hipStream_t s, const PftParams& p, const PftDev& d, uint3
 // epoch: a value that differs from the handle's previous crop launch (non-zero); tags the per-workgroup counts of the one-pass crop
 void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d, bool bbox_from_partials, uint32_t epoch);
 void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t expected_points);
+// no-op launch unless the sorted builder flagged "radix passes too few" (error bit 3): then the single-workgroup build
+void pftk_octree_rescue(hipStream_t s, const PftParams& p, const PftDev& d);
 struct SortBufs {
   unsigned long long* keys[2];
   uint32_t* vals[2];
@@ -205,3 +212,4 @@ void pftk_population(hipStream_t s, const PftParams& p, const PftDev& d, uint32_
 // debug: materialise the (a, q) table from the prefix-sum form
 void pftk_alias_materialize(hipStream_t s, const PftDev& d, uint32_t n, int32_t* a, double* q);
 int pftk_max_lds_bytes();
+int pftk_cur_device();  // current HIP device ordinal, clamped to [0, PFT_MAX_DEVICES)

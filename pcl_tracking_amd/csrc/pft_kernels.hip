@@ -263,6 +263,7 @@ __global__ __launch_bounds__(1024) void k_crop_scatter(const float4* __restrict_
   } else if (threadIdx.x < 6) {
     s6[threadIdx.x] = bbox6[threadIdx.x];
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) hdr->error = 0u;  // error flags are per iteration (the builder sets them)
   // offset of this workgroup = sum of the counts of the workgroups before it
   if (wave_id() == 7) {
     uint32_t t = 0;
@@ -310,7 +311,12 @@ __global__ __launch_bounds__(1024) void k_crop_onepass(const float4* __restrict_
   __shared__ uint32_t s_scan[20];
   __shared__ uint32_t s_base, s_b;
   __shared__ float s6[6];
-  if (threadIdx.x == 0) s_b = atomicAdd(&hdr->crop_ticket, 1u);
+  if (threadIdx.x == 0) {
+    s_b = atomicAdd(&hdr->crop_ticket, 1u);
+    // error flags are per iteration: the first workgroup of the launch clears them (a later workgroup raises bit 2 only
+    // after its bounded spin, long after this store; the builder re-reads bit 2 and adds its own bits)
+    if (s_b == 0u) hdr->error = 0u;
+  }
   if (FROM_PART) {
     reduce_partials(part, nparts, s6);
   } else if (threadIdx.x < 6) {
@@ -385,15 +391,21 @@ __global__ void k_finalize_raw(const double* __restrict__ partial, uint32_t nchu
 // ------------------------------------------------------------------------------------------------
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-static int g_max_lds = -1;
+// cached per device: handles may live on several GPUs of one process (pft_config.device_id)
+static int g_max_lds[PFT_MAX_DEVICES];
+int pftk_cur_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PFT_MAX_DEVICES) dev = 0;
+  return dev;
+}
 int pftk_max_lds_bytes() {
-  if (g_max_lds < 0) {
-    int dev = 0, v = 0;
-    hipGetDevice(&dev);
+  const int dev = pftk_cur_device();
+  if (g_max_lds[dev] <= 0) {
+    int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0) v = 65536;
-    g_max_lds = v;
+    g_max_lds[dev] = v;
   }
-  return g_max_lds;
+  return g_max_lds[dev];
 }
 
 void pftk_pack_reference(hipStream_t s, const pft_point_xyzrgba* d_pts, uint32_t n, int argorder, float4* xyz,
@@ -439,13 +451,12 @@ void pftk_pose_to_matrix(hipStream_t s, const pft_particle* p, uint32_t n, float
   hipLaunchKernelGGL(k_pose_to_matrix, dim3(cdiv(n, 256)), dim3(256), 0, s, p, n, mats);
 }
 void pftk_aabb(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, bool finalize) {
-  static bool attr_set = false;
+  static bool attr_set[PFT_MAX_DEVICES];
   const uint32_t lds_max = (uint32_t)pftk_max_lds_bytes() - 512u;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aabb), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds_max);
-    attr_set = true;
-  }
+  const int dev = pftk_cur_device();
+  if (!attr_set[dev])
+    attr_set[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aabb), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds_max) == hipSuccess;
   uint32_t lds_points = lds_max / 16u;
   uint32_t lds = p.M <= lds_points ? p.M * 16u : 0u;
   hipLaunchKernelGGL(k_aabb, dim3(d.bbox_grid), dim3(1024), lds, s, d.ref_xyz, p.M, d.mats, n_particles, d.bbox_part,

@@ -361,6 +361,12 @@ __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * 
   if (d.p_active) n_particles = *d.p_active;  // KLD variant: particle_num_ lives on the device
   const int D = hdr->depth;
   const uint32_t n_crop = (hdr->error || D <= 0) ? 0u : hdr->n_crop;
+  // A failed crop / octree build leaves this launch without a target (all weights 0): the flag is mirrored into pinned
+  // host memory, and the next host synchronisation point returns it to the caller (pft_get_result & co.)
+  if (hdr->error && blockIdx.x == 0 && threadIdx.x == 0 && d.host_stat) {
+    d.host_stat[2] = hdr->error;
+    d.host_stat[3] |= hdr->error;
+  }
   const uint32_t n_words = hdr->n_words;
   const int use_tab = hdr->use_table;
   const double omin[3] = {hdr->omin[0], hdr->omin[1], hdr->omin[2]};
@@ -491,15 +497,16 @@ extern "C" void pft_debug_set_ablate(int mask) {
 
 void pftk_likelihood(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, bool debug_nn,
                      int num_cus) {
-  static bool attr_set = false;
+  static bool attr_set[PFT_MAX_DEVICES];
   // half of the CU's LDS per workgroup: two 1024-thread workgroups (32 waves, 8 per SIMD) are resident per CU
   uint32_t lds = ((uint32_t)pftk_max_lds_bytes() / (uint32_t)PFT_LIK_WGS_PER_CU) & ~255u;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_likelihood<false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_likelihood<true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  const int dev = pftk_cur_device();
+  if (!attr_set[dev]) {
+    const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_likelihood<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_likelihood<true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set[dev] = e1 == hipSuccess && e2 == hipSuccess;
   }
   if (g_allow_fast < 0) {  // PFT_GENERIC_DESCENT=1: all-generic descent (A/B and parity cross-check)
     const char* e = getenv("PFT_GENERIC_DESCENT");

@@ -590,17 +590,20 @@ __device__ __forceinline__ void build_regs(const PftParams& prm, const PftDev& d
   }
 }
 
+// rescue != 0: launched behind the sorted builder (pft_octree_sorted.hip); returns at once unless that builder found
+// its radix passes too few for the tree's depth (error bit 3), in which case the tree is built here instead
 __global__ __launch_bounds__(PFT_BUILD_THREADS) void k_octree_build(PftParams prm, PftDev d, uint32_t lds_bytes,
-                                                                    int copy_leaf_pts) {
+                                                                    int copy_leaf_pts, int rescue) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ BuildSh S;
   PftHeader* hdr = d.hdr;
+  if (rescue && !(hdr->error & 8u)) return;  // (uniform)
   const uint32_t n = hdr->n_crop;
   const uint32_t tid = threadIdx.x;
 
   STAMP(0);
   if (tid == 0) {
-    S.err = hdr->error & 4u;  // (bit 2: the one-pass crop gave up waiting for a predecessor: sticky)
+    S.err = hdr->error & 4u;  // (bit 2: this iteration's one-pass crop gave up waiting for a predecessor)
     S.ngrow = 0;
     S.depth = 0;
     S.cur = 1;
@@ -702,19 +705,30 @@ __global__ __launch_bounds__(256) void k_leaf_gather(PftDev d) {
   d.leaf_pts[pos] = d.crop_pts[d.leaf_order[pos]];
 }
 
+static void pftk_octree_set_attr() {
+  static bool attr_set[PFT_MAX_DEVICES];
+  const uint32_t lds = ((uint32_t)pftk_max_lds_bytes() - 10240u) & ~15u;
+  const int dev = pftk_cur_device();
+  if (!attr_set[dev])
+    attr_set[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_octree_build),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+}
+
 void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t expected_points) {
-  static bool attr_set = false;
   // static LDS of the kernel (BuildSh ~2.6 KB, the dense top-level arrays 5 KB): leave 10 KB out of the dynamic request
   const uint32_t lds = ((uint32_t)pftk_max_lds_bytes() - 10240u) & ~15u;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_octree_build), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds);
-    attr_set = true;
-  }
+  pftk_octree_set_attr();
   // the crop size of the previous iteration decides who copies the leaf records (either way is correct for any size)
   const int copy_in_kernel = expected_points <= 5000u ? 1 : 0;
-  hipLaunchKernelGGL(k_octree_build, dim3(1), dim3(PFT_BUILD_THREADS), lds, s, p, d, lds, copy_in_kernel);
+  hipLaunchKernelGGL(k_octree_build, dim3(1), dim3(PFT_BUILD_THREADS), lds, s, p, d, lds, copy_in_kernel, 0);
   // at most PFT_SORTED_BUILD_MIN-ish points reach this builder in practice, but any crop (<= N) is legal
   if (!copy_in_kernel)
     hipLaunchKernelGGL(k_leaf_gather, dim3((d.N + 255u) / 256u ? (d.N + 255u) / 256u : 1u), dim3(256), 0, s, d);
+}
+
+// behind the sorted builder: a no-op unless error bit 3 asks for the rebuild (then the whole tree, leaf records included)
+void pftk_octree_rescue(hipStream_t s, const PftParams& p, const PftDev& d) {
+  pftk_octree_set_attr();
+  const uint32_t lds = ((uint32_t)pftk_max_lds_bytes() - 10240u) & ~15u;
+  hipLaunchKernelGGL(k_octree_build, dim3(1), dim3(PFT_BUILD_THREADS), lds, s, p, d, lds, 1, 1);
 }

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(1024) void k_so_replay(PftParams prm, PftDev d, con
   const float4* pts = d.crop_pts;
   const double res = prm.res;
   if (tid == 0) {
-    S.err = hdr->error & 4u;  // (bit 2: the one-pass crop gave up waiting for a predecessor: sticky)
+    S.err = hdr->error & 4u;  // (bit 2: this iteration's one-pass crop gave up waiting for a predecessor)
     S.ngrow = 0;
     S.depth = 0;
     S.cur = 1;
@@ -422,7 +422,13 @@ __global__ __launch_bounds__(1024) void k_so_scan(PftDev d, SortBufs sb, uint32_
     hdr->n_leaves = tot[D];
     hdr->n_words = off + 1;  // + sentinel
     if (d.host_stat) d.host_stat[1] = (uint32_t)D;
-    if (off + 2 > d.max_words || off >= (1u << 24) || 3u * (uint32_t)D > 8u * npass) {  // last: sort too short
+    if (3u * (uint32_t)D > 8u * npass) {
+      // the host sized the radix passes from the previous iteration's depth and this tree is deeper (the codes are not
+      // fully sorted, the counts above mean nothing): not the caller's error -- bit 3 makes k_so_emit stand back and
+      // the rescue launch behind it rebuild the tree
+      hdr->error |= 8u;
+      hdr->n_words = 0;
+    } else if (off + 2 > d.max_words || off >= (1u << 24)) {
       hdr->error |= 1u;
       hdr->n_words = 0;
     }
@@ -535,4 +541,5 @@ void pftk_octree_sorted(hipStream_t s, const PftParams& p, const PftDev& d, cons
   hipLaunchKernelGGL(k_so_count, dim3(ntiles), dim3(256), 0, s, d, sb, buf);
   hipLaunchKernelGGL(k_so_scan, dim3(1), dim3(1024), 0, s, d, sb, (uint32_t)npass);
   hipLaunchKernelGGL(k_so_emit, dim3(ntiles), dim3(256), 0, s, d, sb, buf);
+  if (npass < 8) pftk_octree_rescue(s, p, d);  // 8 passes cover PFT_MAX_DEPTH: nothing to rescue then
 }

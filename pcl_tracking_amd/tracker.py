@@ -267,6 +267,31 @@ class ParticleFilterTracker:
                     octree_min=mn, octree_max=mx, n_leaves=nl.value, n_words=nn.value, point_keys=keys,
                     scan_queries=q.value, scan_points=s.value)
 
+    def debugSetLimits(self, max_words=0, sorted_npass=0):
+        """error-path tests: lower the octree node capacity / fix the sorted builder's radix passes"""
+        self._ensure()
+        self._check(self._L.pft_debug_set_limits(self._h, int(max_words), int(sorted_npass)))
+
+    def debugStateSave(self):
+        """checkpoint of the filter state between two frames (HBM-resident)"""
+        self._check(self._L.pft_debug_state_save(self._h))
+
+    def debugStateRestore(self):
+        """back to the checkpoint: one kernel on the handle's stream"""
+        self._check(self._L.pft_debug_state_restore(self._h))
+
+    def debugInjectError(self, bits):
+        """error-path tests: OR `bits` into the device-side error flags right after the next crop launch"""
+        self._ensure()
+        self._check(self._L.pft_debug_inject_error(self._h, int(bits)))
+
+    def debugHostStat(self):
+        """the pinned status block: last crop size, last depth, flags of the last failed iteration, unreported flags"""
+        self._ensure()
+        out = np.zeros(4, np.uint32)
+        self._check(self._L.pft_debug_get_host_stat(self._h, _ptr(out)))
+        return out
+
     def debugNormalize(self, w):
         self._ensure()
         w = np.array(w, np.float32, copy=True)

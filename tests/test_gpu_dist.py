@@ -84,6 +84,73 @@ def _worker(rank, world, port, outdir, P, frames, seed):
     dist.destroy_process_group()
 
 
+def test_config3_world8_65536_particles_rehearsed_in_one_process(orc):
+    """BASELINE configs[3] at full size -- 65 536 particles sharded 8 192 per rank over 8 ranks, 50 000-point cloud --
+    on ONE GPU.  The box admits at most 6 processes on its card, so the eight ranks are eight handles of this one
+    process (pft_config.rank = 0..7, world_size = 8) and the two exchange steps are done by hand on the device
+    (element-wise max of the eight bbox6 buffers, concatenation of the eight shards): exactly what all-reduce(MAX) and
+    all-gather deliver.  Every rank must reproduce the single 65 536-particle handle bit for bit; raw weights of the
+    gathered population are spot-checked against the oracle inside the global crop box."""
+    import ctypes as C
+
+    import torch
+
+    from pcl_tracking_amd import tracker
+    from pcl_tracking_amd.dist import HipPhases
+
+    P, world, frames, seed = 65536, 8, 2, 1
+    model, cloud = scene.make_model(2048), scene.make_scene(50000)
+    dev = torch.device("cuda", 0)
+    single = tracker.make_reference_tracker(particle_num=P, seed=seed)
+    single.setReferenceCloud(model)
+    single.setTrans(scene.initial_trans())
+    phs = [HipPhases(P, r, world, dev, seed=seed) for r in range(world)]
+    for ph in phs:
+        ph.set_reference(model)
+        ph.set_trans(scene.initial_trans())
+    raw_gathered = None
+    for f in range(frames):
+        single.setInputCloud(cloud)
+        single.compute()
+        want = single.getResult().tobytes()
+        for ph in phs:
+            ph.set_input(cloud)
+            ph.begin_frame()
+        for it in range(2):
+            for ph in phs:
+                ph.phase_a(it)
+            bb = torch.stack([ph.bbox6 for ph in phs]).max(0).values  # all-reduce(MAX)
+            for ph in phs:
+                ph.bbox6.copy_(bb)
+                ph.phase_b()
+            g = torch.cat([ph.shard for ph in phs])  # all-gather, rank order
+            raw_gathered = g.clone()
+            for ph in phs:
+                ph.gathered.copy_(g)
+                ph.phase_c()
+        for r, ph in enumerate(phs):
+            assert ph.get_result().tobytes() == want, (f, r)
+    want_p = single.getParticles().view(np.float32).reshape(-1, 8)
+    for r, ph in enumerate(phs):
+        np.testing.assert_array_equal(ph.get_particles().view(np.float32).reshape(-1, 8), want_p, err_msg="rank %d" % r)
+    # oracle spot check: raw likelihoods of the last iteration's gathered population (before normalisation), a few
+    # particles from every shard, inside the crop box of the whole population
+    pop = raw_gathered.cpu().numpy().view(scene.PARTICLE_DTYPE)
+    bbox = np.zeros(6, np.float32)
+    t0 = phs[0].t
+    t0._check(t0._L.pft_debug_get_bbox(t0._h, bbox.ctypes.data_as(C.c_void_p)))
+    pick = np.concatenate([r * (P // world) + np.random.default_rng(r).choice(P // world, 3, replace=False)
+                           for r in range(world)])
+    o = orc.Tracker(orc.default_config(particle_num=len(pick), threads=0, emulate_pcl_alloc=0))
+    o.set_reference(model)
+    o.set_trans(scene.initial_trans())
+    o.set_input(cloud)
+    O = o.eval_weights(pop[pick], want_nn=False, mats=t0.debugPoseToMatrix(pop[pick]), bbox=bbox.astype(np.float64))
+    a = np.ascontiguousarray(pop["weight"][pick]).view(np.int32).astype(np.int64)
+    b = O["raw"].view(np.int32).astype(np.int64)
+    assert (O["raw"] < 0).any() and np.abs(a - b).max() <= 1, (pop["weight"][pick], O["raw"])
+
+
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_rehearsal_on_one_gpu(tmp_path, orc, world):

@@ -67,6 +67,66 @@ def test_full_size_weights(orc, P, N, organized):
     assert d.max() <= 1, (d.max(), G["raw"][pick], O["raw"])
 
 
+def test_config4_four_objects_8192_particles_on_a_shared_200k_cloud(orc):
+    """BASELINE configs[4] at full size: 4 independent model clouds, 8 192 particles each, one handle + HIP stream
+    each, one shared 200 000-point cloud (the reference's loop over tracker_dict, auto_tracking.cpp:688-697).
+    Independence: enqueued together, the four give bit for bit what each gives alone.  Oracle spot check: some
+    particles of one object's running filter, evaluated by the oracle inside the crop box the GPU found."""
+    from pcl_tracking_amd import tracker
+
+    P, N, frames = 8192, 200000, 2
+    cloud = scene.make_scene(N)
+    models = [scene.make_model(2048, seed=scene.MODEL_SEED + k) for k in range(4)]
+
+    def make(k):
+        t = tracker.make_reference_tracker(particle_num=P, seed=20 + k)
+        t.setReferenceCloud(models[k])
+        t.setTrans(scene.initial_trans())
+        return t
+
+    alone = []
+    for k in range(4):
+        t = make(k)
+        out = []
+        for f in range(frames):
+            t.setInputCloud(cloud)
+            t.compute()
+            out.append(t.getResult().tobytes())
+        out.append(t.getParticles().tobytes())
+        alone.append(out)
+        t.close()
+    ts = [make(k) for k in range(4)]
+    together = [[] for _ in range(4)]
+    for f in range(frames):
+        for t in ts:  # all four enqueued before any result is read: the streams overlap on the device
+            t.setInputCloud(cloud)
+            t.compute()
+        for k, t in enumerate(ts):
+            together[k].append(t.getResult().tobytes())
+    for k, t in enumerate(ts):
+        together[k].append(t.getParticles().tobytes())
+    assert together == alone
+    # the filters do track: each object's pose stays near the start pose (same scene object seen by four models)
+    for t in ts:
+        r = t.getResult()
+        assert abs(float(r["x"]) - scene.GT_POSE[0]) < 0.1 and abs(float(r["z"]) - scene.GT_POSE[2]) < 0.1
+    # oracle spot check on object 2's population
+    g = ts[2]
+    p = g.getParticles()
+    G = g.evalWeights(p)
+    assert len(G["crop_idx"]) > 1000 and (G["raw"] < 0).any()
+    pick = np.random.default_rng(6).choice(P, 24, replace=False)
+    o = orc.Tracker(orc.default_config(particle_num=len(pick), threads=0, emulate_pcl_alloc=0))
+    o.set_reference(models[2])
+    o.set_trans(scene.initial_trans())
+    o.set_input(cloud)
+    O = o.eval_weights(p[pick], want_nn=False, mats=g.debugPoseToMatrix(p[pick]), bbox=G["bbox"].astype(np.float64))
+    np.testing.assert_array_equal(O["crop_idx"], G["crop_idx"])
+    assert O["octree_depth"] == G["octree_depth"]
+    d = ulp_diff(G["raw"][pick], O["raw"])
+    assert d.max() <= 1, (d.max(), G["raw"][pick], O["raw"])
+
+
 def test_concurrent_trackers_are_independent():
     """BASELINE configs[4]: several objects tracked at once, one handle and one HIP stream each"""
     from pcl_tracking_amd import tracker

@@ -1,0 +1,158 @@
+"""Long tracking runs on the GPU against the CPU oracle (run with -m gpu on an MI355X), SURVEY 8a rows A1 + A12.
+
+>= 30 frames of a MOVING object (scene.advance_pose) with input clouds whose cropped size crosses
+PFT_SORTED_BUILD_MIN in both directions, so the run passes through everything a short run never sees: the
+builder switch driven by the previous iteration's crop size (single-workgroup <-> sorted many-workgroup
+builder), its radix-pass guess from the previous depth and the rescue launch behind it, the double-buffered
+particle arrays, the resample epochs, the one-pass crop's launch tags and (KLD variant) a particle count that
+changes every resample.
+
+Two comparisons per configuration:
+  * SAME TRIG  -- the oracle forms pose -> matrix with double sin / cos rounded to float, exactly as the device
+    does (oracle.Tracker.set_trig_mode(1), a test-only switch; PCL's cosf / sinf stays the oracle's default).
+    Both sides then see identical matrices and identical Philox draws; what is left are the documented
+    re-associated double sums (per-particle likelihood sum, weight sum, weighted mean: <= 1 ulp(float) each), so
+    every frame must agree to a few ulp and the particle sets must be the same sets.
+  * OWN TRIG   -- each side with its own sin / cos (glibc cosf / sinf against the device's double -> float): the
+    north_star bar of 1e-4 on the weighted-mean pose; the first frame at which 1e-4 is exceeded is reported
+    (DESIGN.md section 4 records it).
+PARITY UNPINNED: the oracle restates PCL 1.8.0, which is not available here (oracle/pft_oracle.h).
+"""
+import numpy as np
+import pytest
+
+from pcl_tracking_amd import scene
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("x", "y", "z", "roll", "pitch", "yaw")
+FRAMES = 32
+
+
+def ulp_diff(a, b):
+    a = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7FFFFFFF), a)
+    b = np.where(b < 0, -(b & 0x7FFFFFFF), b)
+    return np.abs(a - b)
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from pcl_tracking_amd import tracker
+
+    return tracker
+
+
+_clouds = {}
+
+
+def frame_cloud(f):
+    """the object advances 1 mm / 0.5 deg per frame; the sensor alternates between a sparse organised
+    image (160x120: crops of a few thousand points), a dense one (320x240: crops above PFT_SORTED_BUILD_MIN) and,
+    every eighth frame, the voxel-downsampled 50 000-point cloud of the headline benchmark"""
+    if f not in _clouds:
+        pose = scene.advance_pose(scene.GT_POSE, f)
+        if f % 8 == 5:
+            _clouds[f] = scene.make_scene(50000, obj_pose=pose)
+        elif (f // 3) % 2 == 1:
+            _clouds[f] = scene.make_scene(320 * 240, obj_pose=pose, mode="organized")
+        else:
+            _clouds[f] = scene.make_scene(160 * 120, obj_pose=pose, mode="organized")
+    return _clouds[f]
+
+
+def make_pair(gpu, orc, P, seed, kld, trig_mode):
+    model = scene.make_model(2048)
+    g = gpu.make_reference_tracker(particle_num=P, seed=seed, kld=kld)
+    o = orc.Tracker(orc.default_config(particle_num=P, seed=seed, threads=0, emulate_pcl_alloc=0,
+                                       kld_adaptive=1 if kld else 0))
+    o.set_trig_mode(trig_mode)
+    for ref, tr in ((g.setReferenceCloud, g.setTrans), (o.set_reference, o.set_trans)):
+        ref(model)
+        tr(scene.initial_trans())
+    return g, o
+
+
+@pytest.mark.parametrize("P,kld", [(400, False), (8192, False), (400, True)])
+def test_long_run_same_trig_is_bit_stable(gpu, orc, P, kld):
+    g, o = make_pair(gpu, orc, P, seed=11, kld=kld, trig_mode=1)
+    crops, depths, worst_pose, worst_frame, flipped = [], [], 0.0, -1, 0
+    for f in range(FRAMES):
+        cloud = frame_cloud(f)
+        g.setInputCloud(cloud)
+        o.set_input(cloud)
+        g.compute()
+        assert o.compute() == 0
+        rg, ro = g.getResult(), o.get_result()  # getResult also reports device-side failures of the frame
+        hs = g.debugHostStat()
+        crops.append(int(hs[0]))
+        depths.append(int(hs[1]))
+        assert hs[2] == 0 and hs[3] == 0, (f, hs)
+        pg, po = g.getParticles(), o.get_particles()
+        # KLD variant: the particle count of every frame is the oracle's
+        assert len(pg) == len(po), (f, len(pg), len(po))
+        # the weighted mean is a double tree sum on the device and a sequential float sum in PCL (DESIGN.md
+        # "numerics": ~1e-7), on top of weights that may differ in their last digits
+        a = max(abs(float(rg[k]) - float(ro[k])) for k in KEYS)
+        assert a <= 1e-6, (f, a, rg, ro)
+        if a > worst_pose:
+            worst_pose, worst_frame = a, f
+        assert rg["weight"] == ro["weight"]
+        # particle set: the same draws from the same alias entries.  Poses bit-equal (Box-Muller in double on both
+        # sides; ocml and glibc agree except for rare 1-ulp(double) cases that survive the cast to float).  A raw
+        # weight may differ by 1 ulp (re-associated double sum); when that particle is the minimum or maximum, every
+        # normalised weight moves by ~1e-5 relative, and an alias draw within that distance of its threshold picks
+        # the other entry: such a particle is counted, not tolerated silently
+        dk = np.zeros(len(pg), np.int64)
+        for k in KEYS:
+            dk = np.maximum(dk, ulp_diff(pg[k], po[k]))
+        n_off = int((dk > 1).sum())
+        flipped += n_off
+        assert n_off <= max(1, len(pg) // 2000), (f, n_off)
+        assert (dk == 0).mean() >= 0.998, (f, float((dk == 0).mean()))
+        same = dk <= 1
+        np.testing.assert_allclose(pg["weight"][same], po["weight"][same], rtol=2e-4, atol=1e-12, err_msg="frame %d" % f)
+    # the run really did cross the builder threshold in both directions, and the depth changed on the way
+    big = [c > 18000 for c in crops]
+    assert any(big) and not all(big), crops
+    assert any(big[i] != big[i + 1] for i in range(len(big) - 1)), crops
+    assert len(set(depths)) >= 2, depths
+    if kld:
+        assert len(set(len(frame_cloud(f)) for f in range(FRAMES))) >= 2
+    print("long run P=%d kld=%s: %d frames, crops %d..%d, depths %s, worst pose difference %.3g at frame %d, "
+          "particles that took another alias entry over the run: %d"
+          % (P, kld, FRAMES, min(crops), max(crops), sorted(set(depths)), worst_pose, worst_frame, flipped))
+
+
+@pytest.mark.parametrize("P,kld", [(400, False), (8192, False), (400, True)])
+def test_long_run_own_trig_stays_within_1e_4(gpu, orc, P, kld, record_property):
+    """PCL's cosf / sinf on the oracle side, the device's own trig on the other: 1-ulp differences of matrix
+    entries flip a neighbour now and then, a weight's last digits, eventually one alias draw.  The bar is the
+    north_star's 1e-4 on the weighted-mean pose; the first frame that exceeds it (if any within the run) is
+    reported, and must lie beyond the short runs of test_gpu_parity.py."""
+    g, o = make_pair(gpu, orc, P, seed=11, kld=kld, trig_mode=0)
+    first_bad, worst = None, 0.0
+    for f in range(FRAMES):
+        cloud = frame_cloud(f)
+        g.setInputCloud(cloud)
+        o.set_input(cloud)
+        g.compute()
+        assert o.compute() == 0
+        rg, ro = g.getResult(), o.get_result()
+        a = max(abs(float(rg[k]) - float(ro[k])) for k in KEYS)
+        worst = max(worst, a)
+        if a >= 1e-4 and first_bad is None:
+            first_bad = f
+        if not kld:
+            assert len(g.getParticles()) == P
+    record_property("first_frame_over_1e-4", first_bad)
+    print("own-trig run P=%d kld=%s: worst pose difference %.3g over %d frames, first frame over 1e-4: %s"
+          % (P, kld, worst, FRAMES, first_bad))
+    # the fixed tracker at the benchmark's particle count averages a flipped draw away (1 / 8192 of the weight);
+    # with 400-500 particles a single flipped alias draw moves the mean by up to sigma_rot / P = 2.4e-4
+    if P >= 8192:
+        assert first_bad is None, (first_bad, worst)
+    else:
+        assert first_bad is None or first_bad >= 5, (first_bad, worst)
+        assert worst < 5e-3, worst  # the two filters keep tracking the same object
