@@ -107,6 +107,7 @@ def lib():
     L.orc_tracker_set_bbox_override.argtypes = [vp, vp]
     L.orc_tracker_set_bbox_only.argtypes = [vp, C.c_int]
     L.orc_tracker_set_trig_mode.argtypes = [vp, C.c_int]
+    L.orc_tracker_set_sum_mode.argtypes = [vp, C.c_int]
     L.orc_kld_normal_quantile.argtypes = [f64]
     L.orc_kld_normal_quantile.restype = f64
     L.orc_kld_bound.argtypes = [C.c_int, f64, f64]
@@ -374,6 +375,11 @@ class Tracker:
 
     def fit_ratio(self):
         return lib().orc_tracker_fit_ratio(self.h)
+
+    def set_sum_mode(self, mode):
+        """tests only: 0 = PCL's sequential weight sum and weighted mean (default); 1 = the adjacent-pair tree order the
+        product specifies for its parallel reductions"""
+        lib().orc_tracker_set_sum_mode(self.h, int(mode))
 
     def set_trig_mode(self, mode):
         """tests only: 0 = A1 with cosf / sinf as PCL (default); 1 = double sin / cos rounded to float, as the

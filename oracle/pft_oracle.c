@@ -488,6 +488,71 @@ void orc_normalize_weights(float* w, size_t n, double alpha, double* fit_ratio) 
   }
 }
 
+/* ---- TEST-ONLY summation order (orc_tracker_set_sum_mode(t, 1)) ----
+ * PCL adds the weights (double) and the weighted poses (float) one after the other in index order; a parallel device
+ * cannot, and the product specifies its order instead: the ADJACENT-PAIR TREE over the index range padded with +0.0
+ * to a power of two -- T0[i] = x[i], T(k+1)[i] = Tk[2i] + Tk[2i+1], result = the root -- in double, which any
+ * power-of-two decomposition into threads / waves / workgroups / GPUs reproduces bit for bit
+ * (pcl_tracking_amd/csrc/pft_population.hip).  With this mode, and trig mode 1, the oracle follows the device's
+ * arithmetic exactly, so whole tracking runs can be compared bit for bit (tests/test_gpu_longrun.py).  The
+ * difference from PCL's own order is <= 1 ulp(float) of the weight sum and ~1e-7 of the mean pose. */
+static double tree_sum(double* v, size_t n) { /* destroys v; v has room for the next power of two >= n */
+  size_t m = 1;
+  while (m < n) m <<= 1;
+  for (size_t i = n; i < m; i++) v[i] = 0.0;
+  for (; m > 1; m >>= 1)
+    for (size_t i = 0; i < m / 2; i++) v[i] = v[2 * i] + v[2 * i + 1];
+  return n ? v[0] : 0.0;
+}
+static size_t pow2_at_least(size_t n) {
+  size_t m = 1;
+  while (m < n) m <<= 1;
+  return m;
+}
+
+static void normalize_weights_tree(float* w, size_t n, double alpha, double* fit_ratio) {
+  double w_min = DBL_MAX, w_max = -DBL_MAX;
+  for (size_t i = 0; i < n; i++) {
+    double weight = w[i];
+    if (w_min > weight) w_min = weight;
+    if (weight != 0.0 && w_max < weight) w_max = weight;
+  }
+  if (fit_ratio) *fit_ratio = w_min;
+  if (w_max != w_min) {
+    for (size_t i = 0; i < n; i++)
+      if (w[i] != 0.0) w[i] = (float)exp(1.0 - alpha * (w[i] - w_min) / (w_max - w_min));
+  } else {
+    for (size_t i = 0; i < n; i++) w[i] = 1.0f / (float)n;
+  }
+  double* v = (double*)malloc(sizeof(double) * pow2_at_least(n ? n : 1));
+  for (size_t i = 0; i < n; i++) v[i] = (double)w[i];
+  const double sum = tree_sum(v, n);
+  free(v);
+  if (sum != 0.0) {
+    for (size_t i = 0; i < n; i++) w[i] = w[i] / (float)sum;
+  } else {
+    for (size_t i = 0; i < n; i++) w[i] = 1.0f / (float)n;
+  }
+}
+
+static void weighted_mean_tree(const orc_particle_t* p, size_t n, orc_particle_t* rep) {
+  orc_particle_t r;
+  memset(&r, 0, sizeof(r));
+  r.w = 1.0f;
+  double* v = (double*)malloc(sizeof(double) * pow2_at_least(n ? n : 1));
+  float* out[6] = {&r.x, &r.y, &r.z, &r.roll, &r.pitch, &r.yaw};
+  for (int k = 0; k < 6; k++) {
+    for (size_t i = 0; i < n; i++) {
+      const float c = k == 0 ? p[i].x : k == 1 ? p[i].y : k == 2 ? p[i].z : k == 3 ? p[i].roll : k == 4 ? p[i].pitch : p[i].yaw;
+      v[i] = (double)c * (double)p[i].weight;
+    }
+    *out[k] = (float)tree_sum(v, n);
+  }
+  free(v);
+  r.weight = 1.0f / (float)n;
+  *rep = r;
+}
+
 /* A9  genAliasTable (same file): Walker alias, H stack from the front, L stack from the back */
 void orc_gen_alias_table(const float* w, size_t num, int32_t* a, double* q) {
   if (num == 0) return;
@@ -747,6 +812,7 @@ struct orc_tracker {
   const double* bbox_override; /* tests: x_min,x_max,y_min,y_max,z_min,z_max used instead of calcBoundingBox */
   int bbox_only;               /* tests: stop after calcBoundingBox */
   int trig_mode;               /* tests: 0 = cosf / sinf as PCL (default), 1 = double sin / cos rounded to float */
+  int sum_mode;                /* tests: 0 = PCL's sequential sums (default), 1 = the device's adjacent-pair tree sums */
 };
 
 orc_tracker_t* orc_tracker_create(const orc_config_t* c) {
@@ -757,6 +823,7 @@ orc_tracker_t* orc_tracker_create(const orc_config_t* c) {
 }
 
 void orc_tracker_set_trig_mode(orc_tracker_t* t, int mode) { t->trig_mode = mode; }
+void orc_tracker_set_sum_mode(orc_tracker_t* t, int mode) { t->sum_mode = mode; }
 
 void orc_tracker_destroy(orc_tracker_t* t) {
   if (!t) return;
@@ -975,7 +1042,10 @@ static void tracker_weight(orc_tracker_t* t) {
   /* use_change_detector_ == false: changed_ = true after every weight() */
   t->changed = 1;
   double t0 = omp_get_wtime();
-  orc_normalize_weights(w, P, t->cfg.alpha, &t->fit_ratio);
+  if (t->sum_mode == 1)
+    normalize_weights_tree(w, P, t->cfg.alpha, &t->fit_ratio);
+  else
+    orc_normalize_weights(w, P, t->cfg.alpha, &t->fit_ratio);
   for (size_t i = 0; i < P; i++) t->particles[i].weight = w[i];
   t->stage[4] += omp_get_wtime() - t0;
   free(w);
@@ -1005,7 +1075,10 @@ static void tracker_resample(orc_tracker_t* t) {
 static void tracker_update(orc_tracker_t* t) {
   double t0 = omp_get_wtime();
   orc_particle_t orig = t->rep, r;
-  orc_weighted_mean(t->particles, t->P, &r);
+  if (t->sum_mode == 1)
+    weighted_mean_tree(t->particles, t->P, &r);
+  else
+    orc_weighted_mean(t->particles, t->P, &r);
   t->rep = r;
   t->motion.x = r.x - orig.x; t->motion.y = r.y - orig.y; t->motion.z = r.z - orig.z;
   t->motion.roll = r.roll - orig.roll; t->motion.pitch = r.pitch - orig.pitch; t->motion.yaw = r.yaw - orig.yaw;

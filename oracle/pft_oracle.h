@@ -139,6 +139,9 @@ void orc_tracker_set_matrix_override(orc_tracker_t* t, const float* m16);
 /* tests only: 0 (default) = A1 with cosf / sinf as PCL; 1 = sin / cos in double rounded to float, the way the product's
  * device code forms the matrix -- identical matrices on both sides, for bit-level comparison of long tracking runs */
 void orc_tracker_set_trig_mode(orc_tracker_t* t, int mode);
+/* tests only: 0 (default) = PCL's sequential weight sum (double) and weighted mean (float); 1 = the order the product
+ * specifies for its parallel reductions: adjacent-pair tree over the index range padded to a power of two, in double */
+void orc_tracker_set_sum_mode(orc_tracker_t* t, int mode);
 /* tests of the particle-sharded host logic: crop with this box (the reduction over all ranks) instead of
  * the box of the given particles; bbox_only stops eval_weights after calcBoundingBox */
 void orc_tracker_set_bbox_override(orc_tracker_t* t, const double* bbox6);

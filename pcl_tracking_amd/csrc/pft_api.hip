@@ -365,10 +365,11 @@ static int check_device_error(pft_tracker* t) {
   if (e & 1u) m += " [bit0] octree node capacity exceeded (more than 8 x input points + 64 words, or 2^24 nodes);";
   if (e & 2u) m += " [bit1] octree depth / bounding-box growth steps exceeded (PFT_MAX_DEPTH 30, PFT_MAX_GROW 40);";
   if (e & 4u) m += " [bit2] the one-pass crop gave up waiting for a predecessor workgroup;";
-  if (e & ~7u) m += " [other] " + std::to_string(e & ~7u) + ";";
+  if (e & 16u) m += " [bit4] a device-scope barrier of the population kernel timed out (its workgroups were not co-resident);";
+  if (e & ~23u) m += " [other] " + std::to_string(e & ~23u) + ";";
   m += " the affected iteration(s) ran without a target cloud (all likelihoods zero)";
   t->err = m;
-  return (e & 4u) ? PFT_ERR_HIP : PFT_ERR_CAPACITY;
+  return (e & (4u | 16u)) ? PFT_ERR_HIP : PFT_ERR_CAPACITY;
 }
 
 static int ensure_input_capacity(pft_tracker* t, uint32_t n) {
@@ -818,11 +819,8 @@ extern "C" int pft_compute(pft_tracker* t) {
     {
       ProfScope ps(t, PFT_K_POPULATION);
       // raw weights from the partial sums, then weight()'s normalizeWeight(); use_change_detector_ == false
-      // => changed_ = true => update(); the alias prefix form feeds the next resample
-      // (the sums of the partial sums are taken by a many-workgroup kernel first: the population stage is one
-      // workgroup, and reading P x nchunk doubles through one CU costs more than a launch)
-      pftk_finalize_raw(t->stream, t->prm, t->dev, t->prm.kld ? t->Pcap : t->prm.P_total, t->d_raw_w);
-      pftk_population(t->stream, t->prm, t->dev, t->prm.kld ? t->Pcap : t->prm.P_total, 2, 1, 1, 1);
+      // => changed_ = true => update(); the alias prefix form feeds the next resample: one launch
+      pftk_population(t->stream, t->prm, t->dev, t->prm.kld ? t->Pcap : t->prm.P_total, 1, 1, 1, 1);
     }
     t->changed = true;
   }

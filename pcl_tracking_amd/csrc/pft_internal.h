@@ -71,7 +71,7 @@ struct PftHeader {  // lives in HBM; written by kernels, read by later kernels (
   uint32_t n_crop;
   uint32_t error;   // per iteration (cleared by the crop kernel): bit0 octree capacity exceeded, bit1 depth / growth steps
                     // exceeded, bit2 one-pass crop gave up waiting, bit3 (internal, transient) sorted builder's radix passes
-                    // too few -> the rescue launch rebuilds
+                    // too few -> the rescue launch rebuilds, bit4 a device-scope barrier of the population kernel timed out
   double omin[3], omax[3];
   int32_t depth;
   int32_t use_table;
@@ -110,6 +110,7 @@ struct PftHeader {  // lives in HBM; written by kernels, read by later kernels (
   // reset by the crop kernel of the same iteration)
   uint32_t lik_ctr[PFT_LIK_GROUPS * 16];
   uint32_t crop_ticket;  // one-pass crop: workgroups take their logical index here (the last one resets it)
+  uint32_t pop_bar[4];   // population kernel: arrival counters of its three device-scope barriers + "done" (self-resetting)
 };
 
 struct PftDev {  // device pointers (host-side struct, passed by value)
@@ -143,7 +144,7 @@ struct PftDev {  // device pointers (host-side struct, passed by value)
   double* alias_pref;    // [0,P): running deficit, [P,2P): running excess
   uint32_t* alias_pos;   // [P]
   float* raw_w;          // [P_local] raw likelihood weights, w = -(float) sum of the particle's partial sums (k_finalize_raw)
-  double* pop_part;      // [PFT_POPM_MAX_WGS][16] per-workgroup partials of the many-workgroup population path
+  double* pop_part;      // [PFT_POPM_MAX_WGS][16] per-workgroup values that cross workgroups in the population kernel
   PftHeader* hdr;
   const uint32_t* p_active;  // KLD variant: &hdr->p_active (kernels take the particle count from here), else null
   uint32_t* eg_start;        // exact-NN mode: [eg_cap + 1] first slot of every grid cell
@@ -205,7 +206,7 @@ void pftk_likelihood(hipStream_t s, const PftParams& p, const PftDev& d, uint32_
                      int num_cus);
 void pftk_finalize_raw(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles,
                        float* raw_out /*nullable*/);
-// normalise + update + alias prefix form over part_all[0..n); when partial != null the raw weights are
+// normalise + update + alias prefix form over part_all[0..n) in one launch; from_partials != 0: the raw weights are
 // first formed from the likelihood partial sums (single-GPU path: fuses k_finalize_raw)
 void pftk_population(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n, int from_partials,
                      int do_normalize, int do_mean, int do_alias);

@@ -1,511 +1,372 @@
-// pft_population.hip -- the stages that need the whole particle population, one 1024-thread workgroup,
-// per-particle values held in registers (K particles per thread), ~10 barriers in total:
+// pft_population.hip -- the stages that need the whole particle population, ONE launch of a few co-resident
+// workgroups that meet at three device-scope barriers:
 //   A8  ParticleFilterTracker::normalizeWeight   (tracking/impl/particle_filter.hpp)
-//   A10 ParticleFilterTracker::update            (weighted mean; double tree sum instead of a
-//                                                 sequential float sum: DESIGN.md "numerics")
+//   A10 ParticleFilterTracker::update            (weighted mean; DESIGN.md "numerics")
 //   A9  genAliasTable, in prefix-sum form: PCL's Walker table has the H stack growing from the front and
 //       the L stack from the back of one array, both popped highest-index-first.  With D_i the running
 //       deficit (1-q) over the L list and E_k the running excess (q-1) over the H list, small l_i is
 //       paired with the first h_k whose E_k >= D_(i-1); h_k drops below 1 at the first i with D_i > E_k
 //       (q = 1 + E_k - D_i) and is then itself paired with h_(k+1).  The lists and prefix sums are built
-//       here with one fused scan; the (a[k], q[k]) entry of a drawn k is evaluated on demand by the
+//       here with suffix scans; the (a[k], q[k]) entry of a drawn k is evaluated on demand by the
 //       resample kernel (pft_device_utils.h alias_q / alias_a_small).
+//
+// Layout.  256-thread workgroups; thread t of workgroup g owns the K = 2^a consecutive particles
+// (g * 256 + t) * K + j.  Every phase keeps that ownership, so only a few doubles per workgroup cross workgroups:
+//   phase 0  raw weights (sum of the likelihood partial sums, fused), min / max(!= 0) per workgroup
+//   -- barrier --
+//   phase 1  w <- exp(1 - alpha (w - min) / (max - min)) (zeros stay zero), weight sum per workgroup
+//   -- barrier --
+//   phase 2  w <- w / (float) sum; weighted-pose sums and alias partition totals per workgroup
+//   -- barrier --
+//   phase 3  workgroup 0 finishes the mean (representative state, motion); every workgroup writes its piece of the
+//            alias lists (suffix scans: both stacks pop the highest index first)
+//
+// SUMMATION ORDER (part of the product's specification, restated by the oracle's test-only sum mode 1): the weight
+// sum and the six weighted-pose sums are ADJACENT-PAIR TREES in double over the index range padded with +0.0 to a
+// power of two -- T0[i] = x[i], T(k+1)[i] = Tk[2i] + Tk[2i+1], result = the root.  Thread (pairs of its K values), wave
+// (xor 1, 2, .. 32), workgroup (waves 0+1, 2+3), launch (workgroups pairwise) all follow that tree, so the result does not
+// depend on K, on the number of workgroups, on the number of GPUs, or on which GPU computes it.  PCL adds
+// sequentially (weights in double, poses in float): <= 1 ulp(float) on the sum, ~1e-7 on the pose.
 #include "pft_device_utils.h"
 
-#define STAMP(k) do { if (threadIdx.x == 0) d.hdr->ticks[16 + (k)] = wall_clock64(); } while (0)
+#define STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) d.hdr->ticks[16 + (k)] = wall_clock64(); } while (0)
 
-struct PopSh {
-  double d6[6][16];
-  double dmin[16], dmax[16];
-  uint32_t u[20];
-  double da[20], db[20];
+#define PFT_POPC_THREADS 256
+#define PFT_POPC_SPIN_LIMIT (1u << 22)
+// pop_part[g][..]: per-workgroup values that cross workgroups
+enum { PP_MIN = 0, PP_MAX = 1, PP_SUM = 2, PP_MEAN = 3, PP_CNT = 9, PP_DEF = 10, PP_EXC = 11 };
+
+struct PopcSh {
+  double red[10][4];
+  uint32_t u[4];
+  double da[4], db[4];
 };
 
+// every thread receives the workgroup's adjacent-pair tree sum of each of its NV values
+template <int NV>
+__device__ __forceinline__ void wg_tree_sum(double (&v)[NV], PopcSh& S) {
+  const int lane = lane_id(), w = wave_id();
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) v[k] += __shfl_xor(v[k], o);
+  }
+  __syncthreads();  // (the scratch may still be read from its previous use)
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) S.red[k][w] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; k++) v[k] = (S.red[k][0] + S.red[k][1]) + (S.red[k][2] + S.red[k][3]);
+}
+
 template <int K>
-__device__ __forceinline__ void population_body(const PftParams& prm, const PftDev& d, uint32_t n, int from_partials, int do_norm,
-                                int do_mean, int do_alias, PopSh& S) {
+__device__ __forceinline__ double thread_tree_sum(double (&v)[K]) {
+#pragma unroll
+  for (int s = 1; s < K; s <<= 1) {
+#pragma unroll
+    for (int j = 0; j + s < K; j += 2 * s) v[j] += v[j + s];
+  }
+  return v[0];
+}
+
+// The few doubles per workgroup that cross workgroups travel through device-scope atomics (performed at the level all
+// XCDs share), not through cached loads / stores: the barrier then needs no L2 write-back or invalidate (a pair of
+// __threadfence() costs about 3 us per barrier here; everything bulky stays with the thread that wrote it).
+__device__ __forceinline__ void pub_store(double* p, double v) {
+  atomicExch(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v));
+}
+__device__ __forceinline__ double pub_load(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// Device-scope barrier of the launch's G co-resident workgroups (G <= 256 on a 256-CU part; they are tiny).  Thread 0
+// of a workgroup has published the workgroup's values with pub_store; it waits for those atomics to be performed,
+// arrives, and polls with a bounded spin: a launch that could not get all its workgroups resident in time raises error
+// bit 4 instead of hanging the GPU.
+__device__ __forceinline__ void grid_barrier(PftHeader* hdr, int k, uint32_t G) {
+  if (G <= 1u) {
+    __syncthreads();
+    return;
+  }
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    atomicAdd(&hdr->pop_bar[k], 1u);
+    uint32_t spins = 0;
+    while (__hip_atomic_load(&hdr->pop_bar[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G) {
+      if (++spins > PFT_POPC_SPIN_LIMIT) {
+        atomicOr(&hdr->error, 16u);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+  }
+  __syncthreads();
+}
+
+template <int K>
+__device__ __forceinline__ void population_body(const PftParams& prm, const PftDev& d, uint32_t n, int from_partials,
+                                                int do_norm, int do_mean, int do_alias, PopcSh& S) {
   pft_particle* P = d.part_all;
-  const uint32_t tid = threadIdx.x;
-  const int lane = lane_id(), w = wave_id(), nw = blockDim.x >> 6;
-  constexpr uint32_t NT = PFT_POP_THREADS;
+  PftHeader* hdr = d.hdr;
+  const uint32_t tid = threadIdx.x, g = blockIdx.x, G = gridDim.x;
+  const int lane = lane_id(), w = wave_id();
+  const uint32_t i0 = (g * PFT_POPC_THREADS + tid) * (uint32_t)K;
+  double* part = d.pop_part;
 
   STAMP(0);
-  // ---- raw (or given) weights, strided ownership: i = tid + j*1024 ----
+  // ---- phase 0: raw (or given) weights ----
   float wr[K];
 #pragma unroll
   for (int j = 0; j < K; j++) {
-    const uint32_t i = tid + j * NT;
+    const uint32_t i = i0 + j;
     wr[j] = 0.0f;
     if (i < n) {
-      if (from_partials == 2) {  // raw weights already summed by k_finalize_raw
-        wr[j] = d.raw_w[i];
-      } else if (from_partials) {  // w = -(float) val, val = sum of the per-chunk likelihood partial sums
+      if (from_partials) {  // w = -(float) val, val = sum of the per-chunk likelihood partial sums, in chunk order
         double v = 0.0;
         for (uint32_t c = 0; c < prm.nchunk; c++) v += d.partial[(size_t)i * prm.nchunk + c];
         wr[j] = -(float)v;
+        if (!do_norm) P[i].weight = wr[j];
+        if (d.raw_w) d.raw_w[i] = wr[j];
       } else {
         wr[j] = P[i].weight;
       }
     }
-    UNROLL_FENCE(j, 4);
   }
-
-  STAMP(1);
   if (do_norm) {
     double wmin = DBL_MAX, wmax = -DBL_MAX;
 #pragma unroll
     for (int j = 0; j < K; j++) {
-      if (tid + j * NT < n) {
-        double x = (double)wr[j];
+      if (i0 + j < n) {
+        const double x = (double)wr[j];
         if (wmin > x) wmin = x;
         if (x != 0.0 && wmax < x) wmax = x;
       }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 1; o < WAVE; o <<= 1) {
       wmin = fmin(wmin, __shfl_xor(wmin, o));
       wmax = fmax(wmax, __shfl_xor(wmax, o));
     }
     if (lane == 0) {
-      S.dmin[w] = wmin;
-      S.dmax[w] = wmax;
-    }
-    __syncthreads();
-    wmin = lane < nw ? S.dmin[lane] : DBL_MAX;
-    wmax = lane < nw ? S.dmax[lane] : -DBL_MAX;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      wmin = fmin(wmin, __shfl_xor(wmin, o));
-      wmax = fmax(wmax, __shfl_xor(wmax, o));
-    }
-    if (tid == 0) d.hdr->fit_ratio = wmin;
-    double sum = 0.0;
-    if (wmax != wmin) {
-#pragma unroll
-      for (int j = 0; j < K; j++) {
-        if (tid + j * NT < n) {
-          if (wr[j] != 0.0f) wr[j] = (float)exp(1.0 - prm.alpha * ((double)wr[j] - wmin) / (wmax - wmin));
-          sum += (double)wr[j];
-        }
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < K; j++) {
-        if (tid + j * NT < n) {
-          wr[j] = 1.0f / (float)n;
-          sum += (double)wr[j];
-        }
-      }
-    }
-    sum = wave_sum(sum);
-    __syncthreads();
-    if (lane == 0) S.dmin[w] = sum;
-    __syncthreads();
-    sum = lane < nw ? S.dmin[lane] : 0.0;
-    sum = wave_sum(sum);
-    if (sum != 0.0) {
-      const float fs = (float)sum;
-#pragma unroll
-      for (int j = 0; j < K; j++) wr[j] = wr[j] / fs;
-    } else {
-#pragma unroll
-      for (int j = 0; j < K; j++) wr[j] = 1.0f / (float)n;
-    }
-  }
-  if (do_norm || from_partials) {
-#pragma unroll
-    for (int j = 0; j < K; j++) {
-      const uint32_t i = tid + j * NT;
-      if (i < n) P[i].weight = wr[j];
-    }
-  }
-
-  STAMP(2);
-  if (do_mean) {
-    double a[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < K; j++) {
-      const uint32_t i = tid + j * NT;
-      if (i < n) {
-        const float4* pp = reinterpret_cast<const float4*>(P + i);
-        const float4 lo = pp[0], hi = pp[1];
-        const double wgt = (double)wr[j];
-        a[0] += (double)lo.x * wgt; a[1] += (double)lo.y * wgt; a[2] += (double)lo.z * wgt;
-        a[3] += (double)hi.x * wgt; a[4] += (double)hi.y * wgt; a[5] += (double)hi.z * wgt;
-      }
-      UNROLL_FENCE(j, 4);
-    }
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-      a[k] = wave_sum(a[k]);
-      if (lane == 0) S.d6[k][w] = a[k];
-    }
-    __syncthreads();
-    if (w < 6) {
-      double r = lane < nw ? S.d6[w][lane] : 0.0;
-      r = wave_sum(r);
-      if (lane == 0) S.d6[w][0] = r;
+      S.da[w] = wmin;
+      S.db[w] = wmax;
     }
     __syncthreads();
     if (tid == 0) {
-      pft_particle orig = d.hdr->rep, r;
-      r.x = (float)S.d6[0][0]; r.y = (float)S.d6[1][0]; r.z = (float)S.d6[2][0]; r.w = 1.0f;
-      r.roll = (float)S.d6[3][0]; r.pitch = (float)S.d6[4][0]; r.yaw = (float)S.d6[5][0];
+      pub_store(&part[g * 16 + PP_MIN], fmin(fmin(S.da[0], S.da[1]), fmin(S.da[2], S.da[3])));
+      pub_store(&part[g * 16 + PP_MAX], fmax(fmax(S.db[0], S.db[1]), fmax(S.db[2], S.db[3])));
+    }
+    grid_barrier(hdr, 0, G);
+    STAMP(1);
+    // ---- phase 1: the exponential, the weight sum ----
+    wmin = tid < G ? pub_load(&part[tid * 16 + PP_MIN]) : DBL_MAX;
+    wmax = tid < G ? pub_load(&part[tid * 16 + PP_MAX]) : -DBL_MAX;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+      wmin = fmin(wmin, __shfl_xor(wmin, o));
+      wmax = fmax(wmax, __shfl_xor(wmax, o));
+    }
+    if (lane == 0) {
+      S.da[w] = wmin;
+      S.db[w] = wmax;
+    }
+    __syncthreads();
+    wmin = fmin(fmin(S.da[0], S.da[1]), fmin(S.da[2], S.da[3]));
+    wmax = fmax(fmax(S.db[0], S.db[1]), fmax(S.db[2], S.db[3]));
+    if (g == 0 && tid == 0) hdr->fit_ratio = wmin;
+    double sv[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      sv[j] = 0.0;
+      if (i0 + j < n) {
+        if (wmax != wmin) {
+          if (wr[j] != 0.0f) wr[j] = (float)exp(1.0 - prm.alpha * ((double)wr[j] - wmin) / (wmax - wmin));
+        } else {
+          wr[j] = 1.0f / (float)n;
+        }
+        sv[j] = (double)wr[j];
+      }
+    }
+    double s1[1] = {thread_tree_sum<K>(sv)};
+    wg_tree_sum<1>(s1, S);
+    if (tid == 0) pub_store(&part[g * 16 + PP_SUM], s1[0]);
+    grid_barrier(hdr, 1, G);
+    STAMP(2);
+    // ---- phase 2: normalise ----
+    s1[0] = tid < G ? pub_load(&part[tid * 16 + PP_SUM]) : 0.0;
+    wg_tree_sum<1>(s1, S);
+    const double sum = s1[0];
+    const float fs = (float)sum;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      if (i0 + j < n) {
+        wr[j] = (sum != 0.0) ? wr[j] / fs : 1.0f / (float)n;
+        P[i0 + j].weight = wr[j];
+      }
+    }
+  }
+
+  // ---- weighted-pose sums and alias partition totals of this workgroup ----
+  uint32_t cntL = 0;
+  double defs = 0.0, excs = 0.0;
+  if (do_mean || do_alias) {
+    double tot[9];
+    if (do_mean) {
+      constexpr int comp[6] = {0, 1, 2, 4, 5, 6};  // x, y, z, roll, pitch, yaw inside the 8-float particle
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        double tv[K];
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+          tv[j] = 0.0;
+          if (i0 + j < n) tv[j] = (double)reinterpret_cast<const float*>(P + i0 + j)[comp[k]] * (double)wr[j];
+        }
+        tot[k] = thread_tree_sum<K>(tv);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; k++) tot[k] = 0.0;
+    }
+    if (do_alias) {
+#pragma unroll
+      for (int j = 0; j < K; j++) {
+        if (i0 + j < n) {
+          const double q = (double)(wr[j] * (float)n);  // float product widened to double, as genAliasTable does
+          if (q < 1.0) {
+            cntL++;
+            defs += 1.0 - q;
+          } else {
+            excs += q - 1.0;
+          }
+        }
+      }
+    }
+    tot[6] = (double)cntL;
+    tot[7] = defs;
+    tot[8] = excs;
+    wg_tree_sum<9>(tot, S);
+    if (tid == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) pub_store(&part[g * 16 + PP_MEAN + k], tot[k]);
+      pub_store(&part[g * 16 + PP_CNT], tot[6]);
+      pub_store(&part[g * 16 + PP_DEF], tot[7]);
+      pub_store(&part[g * 16 + PP_EXC], tot[8]);
+    }
+    grid_barrier(hdr, 2, G);
+    STAMP(3);
+    // ---- phase 3: every workgroup combines the workgroups' values the same way ----
+    double fin[10];
+#pragma unroll
+    for (int k = 0; k < 6; k++) fin[k] = tid < G ? pub_load(&part[tid * 16 + PP_MEAN + k]) : 0.0;
+    const bool after_me = tid < G && tid > g;  // reversed order: the workgroups with higher indices come first
+    fin[9] = tid < G ? pub_load(&part[tid * 16 + PP_CNT]) : 0.0;
+    fin[6] = after_me ? fin[9] : 0.0;
+    fin[7] = after_me ? pub_load(&part[tid * 16 + PP_DEF]) : 0.0;
+    fin[8] = after_me ? pub_load(&part[tid * 16 + PP_EXC]) : 0.0;
+    wg_tree_sum<10>(fin, S);
+    if (do_mean && g == 0 && tid == 0) {
+      pft_particle orig = hdr->rep, r;
+      r.x = (float)fin[0]; r.y = (float)fin[1]; r.z = (float)fin[2]; r.w = 1.0f;
+      r.roll = (float)fin[3]; r.pitch = (float)fin[4]; r.yaw = (float)fin[5];
       r.weight = 1.0f / (float)n;
       pft_particle m;
       m.x = r.x - orig.x; m.y = r.y - orig.y; m.z = r.z - orig.z; m.w = 1.0f;
       m.roll = r.roll - orig.roll; m.pitch = r.pitch - orig.pitch; m.yaw = r.yaw - orig.yaw;
       m.weight = 0.0f;
-      d.hdr->rep = r;
-      d.hdr->motion = m;
+      hdr->rep = r;
+      hdr->motion = m;
     }
-  }
-
-  STAMP(3);
-  if (do_alias) {
-    __threadfence_block();
-    __syncthreads();  // the normalised weights written above are re-read below with a different ownership
-    int32_t* Llist = d.alias_list;
-    int32_t* Hlist = d.alias_list + n;
-    double* Dp = d.alias_pref;      // inclusive running deficit over the L list
-    double* Ep = d.alias_pref + n;  // inclusive running excess over the H list
-    // thread t owns reversed positions [t*Kp, (t+1)*Kp): both stacks pop the highest index first
-    const uint32_t Kp = (n + NT - 1) / NT;
-    const uint32_t r0 = tid * Kp;
-    float wq[K];
-    uint32_t cntL = 0;
-    double defs = 0.0, excs = 0.0;
-#pragma unroll
-    for (int j = 0; j < K; j++) {
-      const uint32_t r = r0 + j;
-      wq[j] = 0.0f;
-      if ((uint32_t)j < Kp && r < n) {
-        wq[j] = P[n - 1 - r].weight;
-        const double q = (double)(wq[j] * (float)n);  // float product widened to double
-        if (q < 1.0) {
-          cntL++;
-          defs += 1.0 - q;
-        } else {
-          excs += q - 1.0;
-        }
+    if (do_alias) {
+      if (g == 0 && tid == 0) {
+        hdr->alias_m = (uint32_t)fin[9];
+        hdr->alias_nh = n - (uint32_t)fin[9];
       }
-      UNROLL_FENCE(j, 8);
-    }
-    STAMP(4);
-    // fused exclusive scan of (cntL, defs, excs) over the workgroup
-    uint32_t iu = cntL;
-    double ia = defs, ib = excs;
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-      uint32_t nu = __shfl_up(iu, o);
-      double na = __shfl_up(ia, o), nb = __shfl_up(ib, o);
-      if (lane >= o) {
-        iu += nu;
-        ia += na;
-        ib += nb;
-      }
-    }
-    if (lane == WAVE - 1) {
-      S.u[w] = iu;
-      S.da[w] = ia;
-      S.db[w] = ib;
-    }
-    __syncthreads();
-    if (w == 0) {
-      uint32_t tu = lane < nw ? S.u[lane] : 0u;
-      double ta = lane < nw ? S.da[lane] : 0.0, tb = lane < nw ? S.db[lane] : 0.0;
-      uint32_t su = tu;
-      double sa = ta, sb = tb;
+      int32_t* Llist = d.alias_list;
+      int32_t* Hlist = d.alias_list + n;
+      double* Dp = d.alias_pref;      // inclusive running deficit over the L list
+      double* Ep = d.alias_pref + n;  // inclusive running excess over the H list
+      // both lists run from the highest particle index down: inclusive SUFFIX scans over the threads of the workgroup
+      uint32_t iu = cntL;
+      double ia = defs, ib = excs;
 #pragma unroll
       for (int o = 1; o < WAVE; o <<= 1) {
-        uint32_t nu = __shfl_up(su, o);
-        double na = __shfl_up(sa, o), nb = __shfl_up(sb, o);
-        if (lane >= o) {
-          su += nu;
-          sa += na;
-          sb += nb;
+        const uint32_t nu = __shfl_down(iu, o);
+        const double na = __shfl_down(ia, o), nb = __shfl_down(ib, o);
+        if (lane + o < WAVE) {
+          iu += nu;
+          ia += na;
+          ib += nb;
         }
       }
-      if (lane < nw) {
-        S.u[lane] = su - tu;
-        S.da[lane] = sa - ta;
-        S.db[lane] = sb - tb;
+      __syncthreads();
+      if (lane == 0) {
+        S.u[w] = iu;
+        S.da[w] = ia;
+        S.db[w] = ib;
       }
-      if (lane == nw - 1) S.u[17] = su;
-    }
-    __syncthreads();
-    uint32_t offL = S.u[w] + iu - cntL;
-    double offD = S.da[w] + ia - defs, offE = S.db[w] + ib - excs;
-    const uint32_t totL = S.u[17];
-    const uint32_t rbeg = r0 < n ? r0 : n;
-    uint32_t offH = rbeg - offL;  // larges before me = elements before me - smalls before me
+      __syncthreads();
+      uint32_t offL = (uint32_t)fin[6] + iu - cntL;
+      double offD = fin[7], offE = fin[8];
+      for (int w2 = 3; w2 > w; w2--) {  // the waves after mine, nearest last (one running sum)
+        offL += S.u[w2];
+        offD += S.da[w2];
+        offE += S.db[w2];
+      }
+      offD += ia - defs;
+      offE += ib - excs;
+      const uint32_t iend = min(i0 + (uint32_t)K, n);
+      const uint32_t before = n - (i0 < n ? iend : n);  // particles with a higher index than mine
+      uint32_t offH = before - offL;
 #pragma unroll
-    for (int j = 0; j < K; j++) {
-      const uint32_t r = r0 + j;
-      if ((uint32_t)j < Kp && r < n) {
-        const uint32_t i = n - 1 - r;
-        const double q = (double)(wq[j] * (float)n);
-        if (q < 1.0) {
-          offD += 1.0 - q;
-          Llist[offL] = (int32_t)i;
-          Dp[offL] = offD;
-          d.alias_pos[i] = offL;
-          offL++;
-        } else {
-          offE += q - 1.0;
-          Hlist[offH] = (int32_t)i;
-          Ep[offH] = offE;
-          d.alias_pos[i] = offH | 0x80000000u;
-          offH++;
+      for (int j = K - 1; j >= 0; j--) {
+        const uint32_t i = i0 + j;
+        if (i < n) {
+          const double q = (double)(wr[j] * (float)n);
+          if (q < 1.0) {
+            offD += 1.0 - q;
+            Llist[offL] = (int32_t)i;
+            Dp[offL] = offD;
+            d.alias_pos[i] = offL;
+            offL++;
+          } else {
+            offE += q - 1.0;
+            Hlist[offH] = (int32_t)i;
+            Ep[offH] = offE;
+            d.alias_pos[i] = offH | 0x80000000u;
+            offH++;
+          }
         }
       }
     }
-    STAMP(5);
-    if (tid == 0) {
-      d.hdr->alias_m = totL;
-      d.hdr->alias_nh = n - totL;
-    }
   }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Populations above 16 particles per thread (P > 16384; the replicated population of a multi-GPU run):
-// the same stages over many workgroups, four launches, per-workgroup partials combined in workgroup order
-// by every workgroup alike (deterministic, identical on every rank).  Workgroup g owns the REVERSED
-// positions r in [g*4096, (g+1)*4096), particle i = n-1-r, so that the alias lists (both stacks pop the
-// highest index first) come out as one exclusive scan over workgroups.
-//   pop_part[g][0..11] = {min, max(!=0), sum, mean x6, cntL, deficit, excess}
-enum { PM_MIN = 0, PM_MAX = 1, PM_SUM = 2, PM_MEAN = 3, PM_CNT = 9, PM_DEF = 10, PM_EXC = 11 };
-constexpr uint32_t PM_WG = PFT_POPM_THREADS * PFT_POPM_ITEMS;
-
-struct PopmSh {
-  double s[3][20];
-};
-
-// phase A: raw weights (from the likelihood partial sums if asked) and the min / max partials
-__global__ __launch_bounds__(PFT_POPM_THREADS) void k_popm_minmax(PftParams prm, PftDev d, uint32_t n, int from_partials) {
-  __shared__ PopmSh S;
-  pft_particle* P = d.part_all;
-  const uint32_t g = blockIdx.x, tid = threadIdx.x;
-  double wmin = DBL_MAX, wmax = -DBL_MAX;
-  for (int j = 0; j < PFT_POPM_ITEMS; j++) {
-    const uint32_t r = g * PM_WG + j * PFT_POPM_THREADS + tid;
-    if (r >= n) break;
-    const uint32_t i = n - 1 - r;
-    float wf;
-    if (from_partials == 2) {
-      wf = d.raw_w[i];
-      P[i].weight = wf;
-    } else if (from_partials) {
-      double v = 0.0;
-      for (uint32_t c = 0; c < prm.nchunk; c++) v += d.partial[(size_t)i * prm.nchunk + c];
-      wf = -(float)v;
-      P[i].weight = wf;
-    } else {
-      wf = P[i].weight;
-    }
-    const double x = (double)wf;
-    if (wmin > x) wmin = x;
-    if (x != 0.0 && wmax < x) wmax = x;
-  }
-  wmin = block_reduce<double>(wmin, S.s[0], OpMinD(), DBL_MAX);
-  wmax = block_reduce<double>(wmax, S.s[1], OpMaxD(), -DBL_MAX);
-  if (tid == 0) {
-    d.pop_part[g * 16 + PM_MIN] = wmin;
-    d.pop_part[g * 16 + PM_MAX] = wmax;
-  }
-}
-
-// phase B: w <- exp(1 - alpha (w - min)/(max - min)) (zeros kept), per-workgroup sums
-__global__ __launch_bounds__(PFT_POPM_THREADS) void k_popm_transform(PftParams prm, PftDev d, uint32_t n) {
-  __shared__ PopmSh S;
-  pft_particle* P = d.part_all;
-  const uint32_t g = blockIdx.x, tid = threadIdx.x, G = gridDim.x;
-  double wmin = tid < G ? d.pop_part[tid * 16 + PM_MIN] : DBL_MAX;
-  double wmax = tid < G ? d.pop_part[tid * 16 + PM_MAX] : -DBL_MAX;
-  wmin = block_reduce<double>(wmin, S.s[0], OpMinD(), DBL_MAX);
-  wmax = block_reduce<double>(wmax, S.s[1], OpMaxD(), -DBL_MAX);
-  if (g == 0 && tid == 0) d.hdr->fit_ratio = wmin;
-  double sum = 0.0;
-  for (int j = 0; j < PFT_POPM_ITEMS; j++) {
-    const uint32_t r = g * PM_WG + j * PFT_POPM_THREADS + tid;
-    if (r >= n) break;
-    const uint32_t i = n - 1 - r;
-    float wf = P[i].weight;
-    if (wmax != wmin) {
-      if (wf != 0.0f) wf = (float)exp(1.0 - prm.alpha * ((double)wf - wmin) / (wmax - wmin));
-    } else {
-      wf = 1.0f / (float)n;
-    }
-    P[i].weight = wf;
-    sum += (double)wf;
-  }
-  sum = block_reduce<double>(sum, S.s[2], OpAddD(), 0.0);
-  if (tid == 0) d.pop_part[g * 16 + PM_SUM] = sum;
-}
-
-// phase C: w <- w / (float) sum; weighted-mean partials; alias partition partials
-__global__ __launch_bounds__(PFT_POPM_THREADS) void k_popm_normalize(PftParams prm, PftDev d, uint32_t n, int do_norm,
-                                                                    int do_mean, int do_alias) {
-  __shared__ PopmSh S;
-  pft_particle* P = d.part_all;
-  const uint32_t g = blockIdx.x, tid = threadIdx.x, G = gridDim.x;
-  double sum = 0.0;
-  if (do_norm) {
-    sum = tid < G ? d.pop_part[tid * 16 + PM_SUM] : 0.0;
-    sum = block_reduce<double>(sum, S.s[0], OpAddD(), 0.0);
-  }
-  const float fs = (float)sum;
-  double a[6] = {0, 0, 0, 0, 0, 0};
-  double cnt = 0.0, defs = 0.0, excs = 0.0;
-  for (int j = 0; j < PFT_POPM_ITEMS; j++) {
-    const uint32_t r = g * PM_WG + j * PFT_POPM_THREADS + tid;
-    if (r >= n) break;
-    const uint32_t i = n - 1 - r;
-    const float4* pp = reinterpret_cast<const float4*>(P + i);
-    const float4 lo = pp[0], hi = pp[1];
-    float wf = hi.w;
-    if (do_norm) {
-      wf = (sum != 0.0) ? wf / fs : 1.0f / (float)n;
-      P[i].weight = wf;
-    }
-    const double wgt = (double)wf;
-    a[0] += (double)lo.x * wgt; a[1] += (double)lo.y * wgt; a[2] += (double)lo.z * wgt;
-    a[3] += (double)hi.x * wgt; a[4] += (double)hi.y * wgt; a[5] += (double)hi.z * wgt;
-    const double q = (double)(wf * (float)n);
-    if (q < 1.0) {
-      cnt += 1.0;
-      defs += 1.0 - q;
-    } else {
-      excs += q - 1.0;
-    }
-  }
-  if (do_mean) {
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-      const double r = block_reduce<double>(a[k], S.s[k % 3], OpAddD(), 0.0);
-      if (tid == 0) d.pop_part[g * 16 + PM_MEAN + k] = r;
-    }
-  }
-  if (do_alias) {
-    cnt = block_reduce<double>(cnt, S.s[0], OpAddD(), 0.0);
-    defs = block_reduce<double>(defs, S.s[1], OpAddD(), 0.0);
-    excs = block_reduce<double>(excs, S.s[2], OpAddD(), 0.0);
-    if (tid == 0) {
-      d.pop_part[g * 16 + PM_CNT] = cnt;
-      d.pop_part[g * 16 + PM_DEF] = defs;
-      d.pop_part[g * 16 + PM_EXC] = excs;
-    }
-  }
-}
-
-// phase D: the alias lists with their running deficit / excess; workgroup 0 also finishes the mean
-__global__ __launch_bounds__(PFT_POPM_THREADS) void k_popm_finish(PftParams prm, PftDev d, uint32_t n, int do_mean,
-                                                                 int do_alias) {
-  __shared__ PopmSh S;
-  __shared__ uint32_t Su[20];
-  pft_particle* P = d.part_all;
-  const uint32_t g = blockIdx.x, tid = threadIdx.x, G = gridDim.x;
-  if (do_mean && g == 0) {
-    double m[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-      const double v = tid < G ? d.pop_part[tid * 16 + PM_MEAN + k] : 0.0;
-      m[k] = block_reduce<double>(v, S.s[k % 3], OpAddD(), 0.0);
-    }
-    if (tid == 0) {
-      pft_particle orig = d.hdr->rep, r;
-      r.x = (float)m[0]; r.y = (float)m[1]; r.z = (float)m[2]; r.w = 1.0f;
-      r.roll = (float)m[3]; r.pitch = (float)m[4]; r.yaw = (float)m[5];
-      r.weight = 1.0f / (float)n;
-      pft_particle mo;
-      mo.x = r.x - orig.x; mo.y = r.y - orig.y; mo.z = r.z - orig.z; mo.w = 1.0f;
-      mo.roll = r.roll - orig.roll; mo.pitch = r.pitch - orig.pitch; mo.yaw = r.yaw - orig.yaw;
-      mo.weight = 0.0f;
-      d.hdr->rep = r;
-      d.hdr->motion = mo;
-    }
-  }
-  if (!do_alias) return;
-  // totals of the workgroups before mine (and of all, for the header)
-  const double c_ = tid < G ? d.pop_part[tid * 16 + PM_CNT] : 0.0;
-  const double d_ = tid < G ? d.pop_part[tid * 16 + PM_DEF] : 0.0;
-  const double e_ = tid < G ? d.pop_part[tid * 16 + PM_EXC] : 0.0;
-  const double baseL = block_reduce<double>(tid < g ? c_ : 0.0, S.s[0], OpAddD(), 0.0);
-  const double baseD = block_reduce<double>(tid < g ? d_ : 0.0, S.s[1], OpAddD(), 0.0);
-  const double baseE = block_reduce<double>(tid < g ? e_ : 0.0, S.s[2], OpAddD(), 0.0);
-  if (g == 0) {
-    const double totL = block_reduce<double>(c_, S.s[0], OpAddD(), 0.0);
-    if (tid == 0) {
-      d.hdr->alias_m = (uint32_t)totL;
-      d.hdr->alias_nh = n - (uint32_t)totL;
-    }
-  }
-  int32_t* Llist = d.alias_list;
-  int32_t* Hlist = d.alias_list + n;
-  double* Dp = d.alias_pref;
-  double* Ep = d.alias_pref + n;
-  // thread t owns the reversed positions [g*4096 + t*16, +16)
-  const uint32_t r0 = g * PM_WG + tid * PFT_POPM_ITEMS;
-  float wq[PFT_POPM_ITEMS];
-  uint32_t cntL = 0;
-  double defs = 0.0, excs = 0.0;
-#pragma unroll
-  for (int j = 0; j < PFT_POPM_ITEMS; j++) {
-    const uint32_t r = r0 + j;
-    wq[j] = 0.0f;
-    if (r < n) {
-      wq[j] = P[n - 1 - r].weight;
-      const double q = (double)(wq[j] * (float)n);
-      if (q < 1.0) {
-        cntL++;
-        defs += 1.0 - q;
-      } else {
-        excs += q - 1.0;
-      }
-    }
-    UNROLL_FENCE(j, 8);
-  }
-  uint32_t tu;
-  double ta, tb;
-  uint32_t offL = (uint32_t)baseL + block_excl_scan<uint32_t>(cntL, Su, &tu);
-  double offD = baseD + block_excl_scan<double>(defs, S.s[0], &ta);
-  double offE = baseE + block_excl_scan<double>(excs, S.s[1], &tb);
-  uint32_t offH = (r0 < n ? r0 : n) - offL;
-#pragma unroll
-  for (int j = 0; j < PFT_POPM_ITEMS; j++) {
-    const uint32_t r = r0 + j;
-    if (r < n) {
-      const uint32_t i = n - 1 - r;
-      const double q = (double)(wq[j] * (float)n);
-      if (q < 1.0) {
-        offD += 1.0 - q;
-        Llist[offL] = (int32_t)i;
-        Dp[offL] = offD;
-        d.alias_pos[i] = offL;
-        offL++;
-      } else {
-        offE += q - 1.0;
-        Hlist[offH] = (int32_t)i;
-        Ep[offH] = offE;
-        d.alias_pos[i] = offH | 0x80000000u;
-        offH++;
+  STAMP(4);
+  // the last workgroup through resets the barrier counters for the next launch; a failed launch tells the host
+  if (G > 1u && tid == 0) {
+    const uint32_t done = atomicAdd(&hdr->pop_bar[3], 1u);
+    if (done == G - 1u) {
+      atomicExch(&hdr->pop_bar[0], 0u);
+      atomicExch(&hdr->pop_bar[1], 0u);
+      atomicExch(&hdr->pop_bar[2], 0u);
+      atomicExch(&hdr->pop_bar[3], 0u);
+      const uint32_t e = __hip_atomic_load(&hdr->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((e & 16u) && d.host_stat) {
+        d.host_stat[2] = e;
+        d.host_stat[3] |= e;
       }
     }
   }
 }
 
-__global__ __launch_bounds__(PFT_POP_THREADS) void k_population(PftParams prm, PftDev d, uint32_t n,
-                                                               int from_partials, int do_norm, int do_mean,
-                                                               int do_alias) {
-  __shared__ PopSh S;
-  if (d.p_active) n = *d.p_active;  // KLD variant: particle_num_ lives on the device
-  const uint32_t per = (n + PFT_POP_THREADS - 1) / PFT_POP_THREADS;
-  if (per <= 1) population_body<1>(prm, d, n, from_partials, do_norm, do_mean, do_alias, S);
-  else if (per <= 2) population_body<2>(prm, d, n, from_partials, do_norm, do_mean, do_alias, S);
-  else if (per <= 4) population_body<4>(prm, d, n, from_partials, do_norm, do_mean, do_alias, S);
-  else if (per <= 8) population_body<8>(prm, d, n, from_partials, do_norm, do_mean, do_alias, S);
-  else population_body<16>(prm, d, n, from_partials, do_norm, do_mean, do_alias, S);  // launcher: n <= 16384
+template <int K>
+__global__ __launch_bounds__(PFT_POPC_THREADS) void k_population(PftParams prm, PftDev d, uint32_t n, int from_partials,
+                                                                int do_norm, int do_mean, int do_alias) {
+  __shared__ PopcSh S;
+  if (d.p_active) n = *d.p_active;  // KLD variant: particle_num_ lives on the device (the grid covers the capacity)
+  population_body<K>(prm, d, n, from_partials, do_norm, do_mean, do_alias, S);
 }
 
 // debug / test hook: the explicit (a, q) table of genAliasTable from the prefix-sum form
@@ -521,20 +382,23 @@ __global__ void k_alias_materialize(const pft_particle* __restrict__ P, AliasVie
   a[k] = (v.pos[k] >> 31) ? a_large : alias_a_small(v, k);
 }
 
+// n = particles (KLD variant: the capacity; the kernel reads the live count).  from_partials != 0: the raw weights are
+// first formed from the likelihood partial sums of d.partial (fuses k_finalize_raw); d.raw_w, if set, receives them.
 void pftk_population(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n, int from_partials,
                      int do_normalize, int do_mean, int do_alias) {
-  if (n < PFT_POPM_MIN) {
-    hipLaunchKernelGGL(k_population, dim3(1), dim3(PFT_POP_THREADS), 0, s, p, d, n, from_partials, do_normalize,
-                       do_mean, do_alias);
-    return;
+  if (!n) return;
+  uint32_t K = 1;
+  while ((n + PFT_POPC_THREADS * K - 1) / (PFT_POPC_THREADS * K) > PFT_POPM_MAX_WGS) K <<= 1;  // n <= PFT_MAX_PARTICLES: K <= 16
+  uint32_t G = 1;
+  while (G * PFT_POPC_THREADS * K < n) G <<= 1;  // a power of two: the workgroups are the upper levels of the sum trees
+  const dim3 grid(G), block(PFT_POPC_THREADS);
+  switch (K) {
+    case 1: hipLaunchKernelGGL(k_population<1>, grid, block, 0, s, p, d, n, from_partials, do_normalize, do_mean, do_alias); break;
+    case 2: hipLaunchKernelGGL(k_population<2>, grid, block, 0, s, p, d, n, from_partials, do_normalize, do_mean, do_alias); break;
+    case 4: hipLaunchKernelGGL(k_population<4>, grid, block, 0, s, p, d, n, from_partials, do_normalize, do_mean, do_alias); break;
+    case 8: hipLaunchKernelGGL(k_population<8>, grid, block, 0, s, p, d, n, from_partials, do_normalize, do_mean, do_alias); break;
+    default: hipLaunchKernelGGL(k_population<16>, grid, block, 0, s, p, d, n, from_partials, do_normalize, do_mean, do_alias); break;
   }
-  const uint32_t G = (n + PM_WG - 1) / PM_WG;  // <= PFT_POPM_MAX_WGS (pft_create caps particle_num)
-  const dim3 grid(G), block(PFT_POPM_THREADS);
-  if (do_normalize || from_partials) hipLaunchKernelGGL(k_popm_minmax, grid, block, 0, s, p, d, n, from_partials);
-  if (do_normalize) hipLaunchKernelGGL(k_popm_transform, grid, block, 0, s, p, d, n);
-  if (do_normalize || do_mean || do_alias)
-    hipLaunchKernelGGL(k_popm_normalize, grid, block, 0, s, p, d, n, do_normalize, do_mean, do_alias);
-  if (do_mean || do_alias) hipLaunchKernelGGL(k_popm_finish, grid, block, 0, s, p, d, n, do_mean, do_alias);
 }
 
 void pftk_alias_materialize(hipStream_t s, const PftDev& d, uint32_t n, int32_t* a, double* q) {

@@ -82,6 +82,11 @@ def test_too_deep_tree_is_reported(gpu):
     t.setReferenceCloud(pts)
     t.setTrans(np.eye(4, dtype=np.float32))
     t.setInputCloud(pts)
+    # identity poses: the crop box is the model's own AABB and keeps both clusters (a rotation of 1e-3 rad would swing
+    # the far cluster by kilometres and leave it outside)
+    p = np.zeros(16, scene.PARTICLE_DTYPE)
+    p["w"], p["weight"] = 1.0, 1.0 / 16
+    t.setParticles(p)
     t.compute()
     with pytest.raises(PftError) as e:
         t.synchronize()
@@ -121,10 +126,10 @@ def test_eval_weights_reports_the_flag(gpu, data):
     gt = scene.model_gt_pose()
     for k, name in enumerate(KEYS):
         p[name] = gt[k]
-    t.debugInjectError(1)
+    t.debugInjectError(4)  # (bits 0 / 1 belong to the builder, which starts from the crop's bit 2 alone)
     with pytest.raises(PftError) as e:
         t.evalWeights(p)
-    assert e.value.status == 6
+    assert e.value.status == 5
     G = t.evalWeights(p)
     assert (G["raw"] < 0).all()
 
@@ -165,8 +170,12 @@ def test_depth_jump_between_computes_with_the_sorted_builder(gpu, data, monkeypa
             p[name] = gt[k] + rng.normal(0, sig_t if k < 3 else sig_r, n)
         return p
 
-    tiny = scene.make_model(64, seed=3)  # a 64-point model: shallow crop
+    tiny = scene.make_model(64, seed=3)
     cloud = data["scene"]
+    # first evaluation: only the two dozen input points nearest to the object centre exist (a crop a few centimetres
+    # wide, depth <= 4); second: the whole scene under particles spread over metres (depth 9)
+    dist2 = (cloud["x"] - gt[0]) ** 2 + (cloud["y"] - gt[1]) ** 2 + (cloud["z"] - gt[2]) ** 2
+    near = cloud[np.sort(np.argsort(dist2)[:24])]
     tight, wide = particles(0.001, 0.01), particles(1.5, 1.0)
     out = {}
     for builder in ("single", "sorted"):
@@ -174,8 +183,9 @@ def test_depth_jump_between_computes_with_the_sorted_builder(gpu, data, monkeypa
         t = gpu.make_reference_tracker(particle_num=64, seed=1)
         t.setReferenceCloud(tiny)
         t.setTrans(scene.initial_trans())
-        t.setInputCloud(cloud)
+        t.setInputCloud(near)
         a = t.evalWeights(tight, want_nn=True)
+        t.setInputCloud(cloud)
         b = t.evalWeights(wide, want_nn=True)
         assert (t.debugHostStat()[2:] == 0).all()
         out[builder] = (a, b)

@@ -107,9 +107,10 @@ def test_config4_four_objects_8192_particles_on_a_shared_200k_cloud(orc):
         together[k].append(t.getParticles().tobytes())
     assert together == alone
     # the filters do track: each object's pose stays near the start pose (same scene object seen by four models)
+    gt = scene.model_gt_pose()
     for t in ts:
         r = t.getResult()
-        assert abs(float(r["x"]) - scene.GT_POSE[0]) < 0.1 and abs(float(r["z"]) - scene.GT_POSE[2]) < 0.1
+        assert abs(float(r["x"]) - gt[0]) < 0.1 and abs(float(r["z"]) - gt[2]) < 0.1, (r, gt)
     # oracle spot check on object 2's population
     g = ts[2]
     p = g.getParticles()
