@@ -19,6 +19,9 @@ HEADERS = ["pft_internal.h", "pft_device_utils.h", os.path.join("..", "..", "inc
 # compares float sums, so contraction would flip near-ties (DESIGN.md "numerics").
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+    # the SLP vectoriser packs adjacent f32 adds / muls into v_pk_add_f32 / v_pk_mul_f32, which issue at 1.1x the
+    # scalar rate on gfx950 and cost v_mov shuffles on top: k_likelihood 215 -> 205 us without it
+    "-fno-slp-vectorize",
     "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
 ]
 

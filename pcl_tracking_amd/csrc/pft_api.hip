@@ -55,7 +55,6 @@ struct pft_tracker {
   int32_t* d_crop_idx = nullptr;
   uint32_t* d_words = nullptr;
   uint32_t max_words = 0;
-  float* d_centers = nullptr;
   uint16_t* d_jump = nullptr;
   uint32_t* d_ref_perm = nullptr;
   float4* d_leaf_pts = nullptr;
@@ -318,7 +317,6 @@ static void sync_dev(pft_tracker* t) {
   d.crop_idx = t->d_crop_idx;
   d.words = t->d_words;
   d.max_words = t->max_words;
-  d.centers = t->d_centers;
   d.jump = t->d_jump;
   d.ref_perm = t->d_ref_perm;
   d.leaf_pts = t->d_leaf_pts;
@@ -490,7 +488,6 @@ extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
   A(dalloc(&t->d_mats, Pl * 12));
   A(dalloc(&t->d_bbox_part, (size_t)t->num_cus * 6));
   A(dalloc(&t->d_bbox6, 8));
-  A(dalloc(&t->d_centers, (size_t)3 * (2u << PFT_TABLE_MAX_DEPTH)));
   A(dalloc(&t->d_jump, (size_t)1 << (3 * PFT_JUMP_MAX_LEVEL)));
   A(dalloc(&t->d_alias_list, 2 * Pt));
   A(dalloc(&t->d_alias_pref, 2 * Pt));
@@ -552,7 +549,7 @@ extern "C" void pft_destroy(pft_tracker* t) {
   dfree(t->d_ref_raw); dfree(t->d_ref_xyz); dfree(t->d_ref_hsv);
   dfree(t->d_in_raw); dfree(t->d_in_pts);
   dfree(t->d_part[0]); dfree(t->d_part[1]); dfree(t->d_mats); dfree(t->d_bbox_part); dfree(t->d_bbox6);
-  dfree(t->d_crop_counts); dfree(t->d_crop_slots); dfree(t->d_crop_pts); dfree(t->d_crop_idx); dfree(t->d_words); dfree(t->d_centers); dfree(t->d_jump); dfree(t->d_ref_perm);
+  dfree(t->d_crop_counts); dfree(t->d_crop_slots); dfree(t->d_crop_pts); dfree(t->d_crop_idx); dfree(t->d_words); dfree(t->d_jump); dfree(t->d_ref_perm);
   dfree(t->d_leaf_pts); dfree(t->d_leaf_order); dfree(t->d_pt_node); dfree(t->d_pt_key); dfree(t->d_pt_tmp);
   dfree(t->d_pt_key64); dfree(t->sort.keys[0]); dfree(t->sort.keys[1]); dfree(t->sort.vals[0]); dfree(t->sort.vals[1]);
   dfree(t->sort.hist); dfree(t->sort.tile_cnt); dfree(t->sort.tile_box); if (t->h_stat) hipHostFree(t->h_stat);

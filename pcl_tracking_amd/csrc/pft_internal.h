@@ -9,7 +9,7 @@
 //   crop_pts            float4[N]   cropped points {x,y,z,h|s<<8|v<<16}, input order            (A4)
 //   words               u32[]       linearised octree: branch = mask | child_base<<8, levels contiguous,
 //                                   leaf = start offset into leaf_pts (+ one sentinel)          (A5)
-//   centers             float[3][2^(D+1)] per-level per-axis voxel-centre tables                 (A6)
+//   (per-level per-axis voxel-centre tables: formed in LDS by the likelihood kernel from depth + box)      (A6)
 //   leaf_pts            float4[N]   cropped points in leaf order (insertion order inside a leaf)
 //   partial             double[P_local*nchunk] per (particle, reference chunk) likelihood sums   (A7)
 //   alias_list/pref/pos prefix-sum form of the Walker alias table over all P particles          (A9)
@@ -130,7 +130,6 @@ struct PftDev {  // device pointers (host-side struct, passed by value)
   int32_t* crop_idx;
   uint32_t* words;
   uint32_t max_words;
-  float* centers;
   uint16_t* jump;           // [2^(3*PFT_JUMP_MAX_LEVEL)]
   const uint32_t* ref_perm; // sorted reference position -> index in the caller's reference cloud
   float4* leaf_pts;

@@ -67,6 +67,14 @@ __device__ __forceinline__ bool face_violation(uint32_t kx, uint32_t ky, uint32_
   return v;
 }
 
+// number of trailing zeros (query near the low face) / trailing ones (near the high face) of a key coordinate: the largest
+// cell size, as a power of two, whose face the query's leaf-cell face lies on; -1 when the query is near neither face
+__device__ __forceinline__ int near_face_level(uint32_t k, bool low, bool high) {
+  const uint32_t t = low ? k : ~k;
+  const uint32_t c = min((uint32_t)(t == 0u ? -1 : __builtin_ctz(t)), 31u);  // one v_ffbl_b32 + v_min_u32
+  return (low | high) ? (int)c : -1;
+}
+
 // LEAF: where the leaf level's start offsets come from -- 0: the node words themselves (W), 1: u16 array in LDS,
 // 2: the u32 words in HBM / L2 (the branch levels alone are in LDS)
 template <bool USE_TAB, bool FAST, bool DEBUG_NN, int LEAF, typename WordPtr>
@@ -155,9 +163,10 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         // of 2^sh leaf cells has its low (high) face on an axis exactly at the query's leaf-cell face iff the low sh
         // key bits are all 0 (all 1): the levels concerned are sh <= V, V = max over the axes that are within
         // the margin of (trailing zeros | trailing ones) of the key.  Queries outside the box take no shortcut.
-        const int vx = fx < mg ? (kx ? __builtin_ctz(kx) : 31) : (fx > mh ? __builtin_ctz(~kx) : -1);
-        const int vy = fy < mg ? (ky ? __builtin_ctz(ky) : 31) : (fy > mh ? __builtin_ctz(~ky) : -1);
-        const int vz = fz < mg ? (kz ? __builtin_ctz(kz) : 31) : (fz > mh ? __builtin_ctz(~kz) : -1);
+        // (branch-free: v_ffbl_b32 returns -1 for a zero operand, which the unsigned minimum turns into the 31 wanted
+        // for key 0; keys never have all 32 bits set)
+        const int vx = near_face_level(kx, fx < mg, fx > mh), vy = near_face_level(ky, fy < mg, fy > mh),
+                  vz = near_face_level(kz, fz < mg, fz > mh);
         const int V = inside ? max(vx, max(vy, vz)) : 31;
         const int lim = min(D, D - 1 - V);  // fast levels are those with lvl < lim
         if (cx.J > 0) {  // (wave-uniform) the jump lands on level J: its cell spans 2^(D-J) leaf cells, D-J > V
@@ -211,7 +220,9 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         // pointSquaredDist: Vector3f difference, squaredNorm = x2 + (y2 + z2)
         float dx0 = cx0 - qx, dx1 = cx1 - qx, dy0 = cy0 - qy, dy1 = cy1 - qy, dz0 = cz0 - qz, dz1 = cz1 - qz;
         float X0 = dx0 * dx0, X1 = dx1 * dx1, Y0 = dy0 * dy0, Y1 = dy1 * dy1, Z0 = dz0 * dz0, Z1 = dz1 * dz1;
-        float yz[4] = {Y0 + Z0, Y0 + Z1, Y1 + Z0, Y1 + Z1};
+        const float yz[4] = {Y0 + Z0, Y0 + Z1, Y1 + Z0, Y1 + Z1};
+        // (a tournament over integer keys -- absent children as all-ones, strict comparisons from the right -- needs 36
+        // instructions instead of these 48 and measured 2 % SLOWER: 209.6 against 204.9 us)
         float best = INFINITY;
         uint32_t bc = 0;
 #pragma unroll
@@ -409,7 +420,20 @@ __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * 
     lut_h[i] = (float)i / 180.0f;
     lut_s[i] = (float)i / 255.0f;
   }
-  for (uint32_t i = threadIdx.x; i < 3u * per_axis; i += blockDim.x) tab[i] = d.centers[i];
+  // per-level per-axis voxel-centre tables, centre(level l, key k) = (float)((k + 0.5) * res * 2^(D-l) + min) exactly as
+  // genVoxelCenterFromOctreeKey; entry 2^l - 2 + k.  Formed here, a few entries per thread, instead of by the one
+  // workgroup of the builder (4.6 us there) and a global round trip.
+  for (uint32_t e = threadIdx.x; e < 3u * per_axis; e += blockDim.x) {
+    const uint32_t a = e / per_axis, r = e - a * per_axis;
+    float c = 0.0f;
+    if (r + 2u < per_axis) {
+      const uint32_t l = 31u - (uint32_t)__clz((int)(r + 2u));
+      const uint32_t k = r + 2u - (1u << l);
+      const double vs = prm.res * (double)(1u << (D - (int)l));
+      c = (float)(((double)k + 0.5) * vs + omin[a]);
+    }
+    tab[e] = c;
+  }
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(d.jump);
     uint32_t* dst = reinterpret_cast<uint32_t*>(ljump);

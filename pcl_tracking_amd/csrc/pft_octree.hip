@@ -10,8 +10,8 @@
 //      child_base; children of a node are contiguous and ordered by child index
 //   4. leaves: counts -> starts (+ sentinel); points ranked by insertion index inside their leaf
 //      (OctreeContainerPointIndices keeps push_back order, and the leaf scan keeps the first minimum)
-//   5. per-level per-axis voxel-centre tables (genVoxelCenterFromOctreeKey), double -> float
-// Output in HBM: words[], leaf_pts[], leaf_order[], centers[], header.
+//   (the per-level per-axis voxel-centre tables of genVoxelCenterFromOctreeKey are formed by the likelihood kernel)
+// Output in HBM: words[], leaf_pts[], leaf_order[], jump[], header.
 #include "pft_device_utils.h"
 
 #define STAMP(k) do { if (threadIdx.x == 0) d.hdr->ticks[k] = wall_clock64(); } while (0)
@@ -40,7 +40,9 @@ __device__ void box_init(BuildSh& S, float4 p0, double res) {
     mk = k > mk ? k : mk;
   }
   unsigned mv = mk > 2u ? mk : 2u;
-  double l2 = log((double)mv) / log(2.0);
+  // getKeyBitSize: ceil(log2(max key) - eps), at least... mv is 2 for the one-point box (log(2)/log(2) == 1.0 exactly):
+  // the two double logarithms are only evaluated in the general case
+  double l2 = mv == 2u ? 1.0 : log((double)mv) / log(2.0);
   unsigned dep = (unsigned)ceil(l2 - (double)FLT_EPSILON);
   if (dep > 32u) dep = 32u;
   double side = (double)(1u << dep) * res - epsd;
@@ -647,23 +649,11 @@ __global__ __launch_bounds__(PFT_BUILD_THREADS) void k_octree_build(PftParams pr
     for (uint32_t pos = tid; pos < n; pos += blockDim.x) d.leaf_pts[pos] = d.crop_pts[d.leaf_order[pos]];
   }
 
-  // ---- voxel-centre tables: centre(level l, key k) = (float)((k + 0.5) * res*2^(D-l) + min) ----
+  // (the per-level voxel-centre tables are formed by the likelihood workgroups themselves, in LDS, from depth + box)
   const int use_table = (ok && D <= PFT_TABLE_MAX_DEPTH) ? 1 : 0;
-  if (use_table) {
-    const uint32_t per_axis = (2u << D);  // entry 2^l - 2 + k for level l = 1..D, key k
-    for (uint32_t e = tid; e < 3u * per_axis; e += blockDim.x) {
-      uint32_t a = e / per_axis, r = e % per_axis;
-      if (r + 2 >= per_axis) {
-        d.centers[e] = 0.0f;
-        continue;
-      }
-      uint32_t l = 31u - __clz(r + 2u);
-      uint32_t k = r + 2u - (1u << l);
-      double vs = prm.res * (double)(1u << (D - (int)l));
-      d.centers[e] = (float)(((double)k + 0.5) * vs + S.mn[a]);
-    }
-  }
   STAMP(8);
+  // the header: spread over a few threads of different waves (one thread doing all of it -- two double divisions, a dozen
+  // dependent LDS reads, ~50 stores -- was 4 us at the tail of a one-workgroup kernel)
   if (tid == 0) {
     hdr->error = S.err;
     hdr->depth = D;
@@ -672,29 +662,30 @@ __global__ __launch_bounds__(PFT_BUILD_THREADS) void k_octree_build(PftParams pr
     hdr->build_path = path;
     if (d.host_stat) d.host_stat[1] = (uint32_t)D;
     hdr->jump_level = (ok && use_table) ? S.jump : 0;
-    {
-      // safety margin of the fast descent (DESIGN.md "fast descent"): float rounding of the voxel centres
-      // (<= ulp(max |coordinate|)) and of the squared-distance sums (<= 40 u s_top) can only reorder two
-      // children when the query is this close to a cell face
-      double maxabs = 0.0;
-      for (int a = 0; a < 3; a++) maxabs = fmax(maxabs, fmax(fabs(S.mn[a]), fabs(S.mx[a])));
-      const double eta = maxabs * 1.1920928955078125e-07;
-      const double s_top = prm.res * (double)(1u << (D > 0 ? D - 1 : 0));
-      const double E = 9.0 * eta + 40.0 * 5.9604644775390625e-08 * s_top;
-      double mc = 2.0 * E / prm.res + 1.0e-3;
-      hdr->margin_cells = (float)(mc < 0.25 ? mc : 1.0);  // >= 0.5: fast descent never taken
-      for (int a = 0; a < 3; a++) hdr->ominf[a] = (float)S.mn[a];
-      hdr->inv_res = (float)(1.0 / prm.res);
-    }
     hdr->n_leaves = ok ? n_leaves : 0;
     hdr->leaf_start = ok ? leaf_start : 0;
     hdr->n_words = ok ? leaf_start + n_leaves + 1 : 0;
-    for (int a = 0; a < 3; a++) {
-      hdr->omin[a] = n > 0 ? S.mn[a] : 0.0;
-      hdr->omax[a] = n > 0 ? S.mx[a] : 0.0;
-    }
-    for (int l = 0; l <= D + 1 && l < PFT_MAX_DEPTH + 3; l++) hdr->lvl_start[l] = S.lvl[l];
   }
+  if (tid == 64) {
+    // safety margin of the fast descent (DESIGN.md "fast descent"): float rounding of the voxel centres
+    // (<= ulp(max |coordinate|)) and of the squared-distance sums (<= 40 u s_top) can only reorder two
+    // children when the query is this close to a cell face
+    double maxabs = 0.0;
+    for (int a = 0; a < 3; a++) maxabs = fmax(maxabs, fmax(fabs(S.mn[a]), fabs(S.mx[a])));
+    const double eta = maxabs * 1.1920928955078125e-07;
+    const double s_top = prm.res * (double)(1u << (D > 0 ? D - 1 : 0));
+    const double E = 9.0 * eta + 40.0 * 5.9604644775390625e-08 * s_top;
+    double mc = 2.0 * E / prm.res + 1.0e-3;
+    hdr->margin_cells = (float)(mc < 0.25 ? mc : 1.0);  // >= 0.5: fast descent never taken
+  }
+  if (tid == 128) hdr->inv_res = (float)(1.0 / prm.res);
+  if (tid >= 192 && tid < 195) {
+    const int a = (int)tid - 192;
+    hdr->ominf[a] = (float)S.mn[a];
+    hdr->omin[a] = n > 0 ? S.mn[a] : 0.0;
+    hdr->omax[a] = n > 0 ? S.mx[a] : 0.0;
+  }
+  if (tid >= 256 && tid < 256 + PFT_MAX_DEPTH + 3 && (int)tid - 256 <= D + 1) hdr->lvl_start[tid - 256] = S.lvl[tid - 256];
 }
 
 // leaf-ordered point records for the likelihood kernel's leaf scan: leaf_pts[pos] = crop_pts[leaf_order[pos]]

@@ -170,20 +170,7 @@ __global__ __launch_bounds__(1024) void k_so_replay(PftParams prm, PftDev d, con
   const bool ok = n > 0 && !S.err && D > 0;
   const int use_table = (ok && D <= PFT_TABLE_MAX_DEPTH) ? 1 : 0;
   const int J = (D >= 4 && D <= PFT_TABLE_MAX_DEPTH) ? (D - 1 < PFT_JUMP_MAX_LEVEL ? D - 1 : PFT_JUMP_MAX_LEVEL) : 0;
-  if (use_table) {
-    const uint32_t per_axis = (2u << D);
-    for (uint32_t e = tid; e < 3u * per_axis; e += nt) {
-      uint32_t a = e / per_axis, r = e % per_axis;
-      if (r + 2 >= per_axis) {
-        d.centers[e] = 0.0f;
-        continue;
-      }
-      uint32_t l = 31u - __clz(r + 2u);
-      uint32_t k = r + 2u - (1u << l);
-      double vs = res * (double)(1u << (D - (int)l));
-      d.centers[e] = (float)(((double)k + 0.5) * vs + S.mn[a]);
-    }
-  }
+  // (the per-level voxel-centre tables are formed by the likelihood workgroups themselves, in LDS, from depth + box)
   if (J > 0) {
     uint32_t* jz = reinterpret_cast<uint32_t*>(d.jump);
     for (uint32_t j = tid; j < (1u << (3 * J - 1)); j += nt) jz[j] = 0u;
