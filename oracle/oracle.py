@@ -39,7 +39,7 @@ class Config(C.Structure):
 
 def build(force=False):
     """Compile the C restatement with the committed Makefile (building the checker is not using it)."""
-    srcs = [os.path.join(_HERE, f) for f in ("pft_oracle.c", "pft_oracle_filters.c", "pft_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("pft_oracle.c", "pft_oracle_filters.c", "pft_oracle_app.c", "pft_oracle.h", "Makefile")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
     return _SO
@@ -120,6 +120,12 @@ def lib():
     L.orc_approx_voxel_grid.restype = sz
     L.orc_voxel_grid.argtypes = [vp, sz, vp, vp]
     L.orc_voxel_grid.restype = sz
+    L.orc_remove_zero_points.argtypes = [vp, sz, vp]
+    L.orc_remove_zero_points.restype = sz
+    L.orc_compute_3d_centroid.argtypes = [vp, sz, C.c_int, vp]
+    L.orc_compute_3d_centroid.restype = sz
+    L.orc_recentre_model.argtypes = [vp, sz, vp, vp, vp]
+    L.orc_object_position.argtypes = [vp, sz, vp, vp, vp]
     _lib = L
     return L
 
@@ -326,6 +332,42 @@ def voxel_grid(pts, leaf=0.01):
     if n == C.c_size_t(-1).value:
         return None
     return out[:n].copy()
+
+
+def remove_zero_points(pts):
+    """removeZeroPoints (/root/reference/src/auto_tracking.cpp:577-595)"""
+    pts = np.ascontiguousarray(pts, POINT_DTYPE)
+    out = np.zeros(max(len(pts), 1), POINT_DTYPE)
+    n = lib().orc_remove_zero_points(_ptr(pts), len(pts), _ptr(out))
+    return out[:n].copy()
+
+
+def compute_3d_centroid(pts, is_dense=True):
+    """pcl::compute3DCentroid<PointT, float> -> (centroid[4] float32, number of points used)"""
+    pts = np.ascontiguousarray(pts, POINT_DTYPE)
+    c = np.zeros(4, np.float32)
+    n = lib().orc_compute_3d_centroid(_ptr(pts), len(pts), 1 if is_dense else 0, _ptr(c))
+    return c, n
+
+
+def recentre_model(pts, centroid):
+    """:663-668 -> (re-centred cloud, trans 4x4 float32 as handed to setTrans)"""
+    pts = np.ascontiguousarray(pts, POINT_DTYPE)
+    c = np.ascontiguousarray(centroid, np.float32)
+    out = np.zeros(max(len(pts), 1), POINT_DTYPE)
+    t = np.zeros(16, np.float32)
+    lib().orc_recentre_model(_ptr(pts), len(pts), _ptr(c), _ptr(out), _ptr(t))
+    return out[:len(pts)].copy(), t.reshape(4, 4)
+
+
+def object_position(reference_full, result):
+    """drawResult + viz_cb: (moved cloud, centroid[4]) of the full-resolution model under the result pose"""
+    ref = np.ascontiguousarray(reference_full, POINT_DTYPE)
+    r = np.ascontiguousarray(result, PARTICLE_DTYPE).reshape(1)
+    moved = np.zeros(max(len(ref), 1), POINT_DTYPE)
+    c = np.zeros(4, np.float32)
+    lib().orc_object_position(_ptr(ref), len(ref), _ptr(r), _ptr(moved), _ptr(c))
+    return moved[:len(ref)].copy(), c
 
 
 class Tracker:

@@ -183,6 +183,17 @@ size_t orc_approx_voxel_grid(const orc_point_t* pts, size_t n, const float leaf[
 /* VoxelGrid (exact, output sorted by voxel index; in-voxel summation in input order); returns #out or (size_t)-1 */
 size_t orc_voxel_grid(const orc_point_t* pts, size_t n, const float leaf[3], orc_point_t* out);
 
+/* ---- host-side steps around the trackers (pft_oracle_app.c) ---- */
+/* removeZeroPoints (/root/reference/src/auto_tracking.cpp:577-595); out: capacity n; returns #kept */
+size_t orc_remove_zero_points(const orc_point_t* in, size_t n, orc_point_t* out);
+/* pcl::compute3DCentroid<PointT, float>; returns the number of points used (0: centroid untouched) */
+size_t orc_compute_3d_centroid(const orc_point_t* pts, size_t n, int is_dense, float centroid[4]);
+/* :663-668 re-centre the model on its centroid; trans16 = the matrix handed to setTrans */
+void orc_recentre_model(const orc_point_t* in, size_t n, const float centroid[4], orc_point_t* out, float trans16[16]);
+/* drawResult + viz_cb (:309-316, :432-433): full-resolution model moved by the result pose (z - 5 mm) and its centroid */
+void orc_object_position(const orc_point_t* reference_full, size_t n, const orc_particle_t* result, orc_point_t* moved,
+                         float centroid[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,30 +58,46 @@ def build(force=False, verbose=False, extra_flags=()):
     return LIB
 
 
-EXAMPLE_SRC = os.path.join(_HERE, "examples", "auto_tracking_amd.cpp")
+EXAMPLES_DIR = os.path.join(_HERE, "examples")
 EXAMPLE_BIN = os.path.join(OUT_DIR, "auto_tracking_amd")
+DIST_EXAMPLE_BIN = os.path.join(OUT_DIR, "dist_tracking_amd")
+_EXAMPLE_DEPS = [os.path.join(EXAMPLES_DIR, "tracking_app.hpp")] + [
+    os.path.join(_HERE, "include", "pft", h) for h in ("particle_filter_tracker.hpp", "filters.hpp", "pcd_io.hpp", "common.hpp")]
 
 
-def build_example(force=False, verbose=False):
-    """the ROS-free C++ driver (host side in the reference's language) over the header-only mirror of the
-    PCL classes and the C-ABI library"""
+def _build_host_program(src, out, extra, force, verbose):
     lib = build()
-    deps = [EXAMPLE_SRC, os.path.join(_HERE, "include", "pft", "particle_filter_tracker.hpp"),
-            os.path.join(_HERE, "include", "pft", "filters.hpp"), os.path.join(_HERE, "include", "pft", "pcd_io.hpp"), lib]
-    if not force and os.path.exists(EXAMPLE_BIN) and all(os.path.getmtime(d) <= os.path.getmtime(EXAMPLE_BIN) for d in deps):
-        return EXAMPLE_BIN
+    deps = [src, lib] + _EXAMPLE_DEPS
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
     root = os.path.dirname(_HERE)
-    cmd = [hipcc(), "-std=c++17", "-O2", "-Wall", "-I", os.path.join(root, "include"), "-I", os.path.join(_HERE, "include"),
-           EXAMPLE_SRC, "-o", EXAMPLE_BIN, "-L", OUT_DIR, "-lpft_hip", "-Wl,-rpath,$ORIGIN"]
+    cmd = [hipcc(), "-std=c++17", "-O2", "-Wall", "-ffp-contract=off", "-I", os.path.join(root, "include"),
+           "-I", os.path.join(_HERE, "include"), src, "-o", out, "-L", OUT_DIR, "-lpft_hip", "-Wl,-rpath,$ORIGIN"] + extra
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("example build failed")
-    return EXAMPLE_BIN
+        raise RuntimeError("example build failed: " + os.path.basename(src))
+    return out
+
+
+def build_example(force=False, verbose=False):
+    """the ROS-free C++ driver (host side in the reference's language) over the header-only mirror of the
+    PCL classes and the C-ABI library: any number of objects, one tracker each"""
+    return _build_host_program(os.path.join(EXAMPLES_DIR, "auto_tracking_amd.cpp"), EXAMPLE_BIN, [], force, verbose)
+
+
+def build_dist_example(force=False, verbose=False):
+    """the C++ multi-GPU host: one process per GPU, pft_dist_* phases with ncclAllReduce / ncclAllGather (RCCL) in
+    between on the handle's stream"""
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    extra = ["-I", os.path.join(rocm, "include"), "-L", os.path.join(rocm, "lib"), "-lrccl", "-lpthread",
+             "-Wl,-rpath," + os.path.join(rocm, "lib")]
+    return _build_host_program(os.path.join(EXAMPLES_DIR, "dist_tracking_amd.cpp"), DIST_EXAMPLE_BIN, extra, force, verbose)
 
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_example(force="--force" in sys.argv, verbose=True))
+    print(build_dist_example(force="--force" in sys.argv, verbose=True))

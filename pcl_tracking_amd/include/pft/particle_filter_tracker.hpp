@@ -203,6 +203,18 @@ class ParticleFilterTracker {
   void setMinIndices(int) {}  // read only when use_normal_ is true
   void setSeed(uint64_t s) { guard(); cfg_.seed = s; }      // PCL's engines are time(0)-seeded
   void setDevice(int id) { guard(); cfg_.device_id = id; }
+  // enqueue on the caller's HIP stream (hipStream_t; nullptr = the default stream) instead of a stream of the handle's own
+  void setStream(void* hip_stream) { guard(); cfg_.stream = hip_stream; cfg_.stream_is_external = 1; }
+  // particle sharding over the GPUs of a node (one process per GPU): this handle owns the global particle ids
+  // [rank * N / world, (rank + 1) * N / world); such a handle is driven through the pft_dist_* phases of pft.h with the
+  // two collectives in between (examples/dist_tracking_amd.cpp), not through compute()
+  void setShard(int rank, int world_size) { guard(); cfg_.rank = rank; cfg_.world_size = world_size; }
+  // compute() is asynchronous and PCL's returns void.  The reference wraps it in try / catch (int)
+  // (auto_tracking.cpp:692-696): with this switch on, compute() waits for the frame and throws the pft_status (an int)
+  // if the device reported a failure for it (octree capacity / depth, crop time-out: pft.h)
+  void setThrowOnFailure(bool b) { throw_on_failure_ = b; }
+  // the handle exists from the first compute() on; create() makes it now (for callers of the C ABI's phase API)
+  bool create() { return ensure(); }
   void setCloudCoherence(const CoherencePtr& c) {
     guard();
     coherence_ = c;
@@ -244,7 +256,7 @@ class ParticleFilterTracker {
     if (dev_input_ && dev_n_) {
       if (!ensure()) return;
       if (check(pft_set_input_device(handle_, dev_input_, dev_n_), "setInputCloudDevice") != PFT_OK) return;
-      check(pft_compute(handle_), "compute");
+      finish(check(pft_compute(handle_), "compute"));
       return;
     }
     if (!input_ || input_->points.empty()) {
@@ -253,13 +265,13 @@ class ParticleFilterTracker {
     }
     if (!ensure()) return;
     if (check(pft_set_input(handle_, input_->points.data(), input_->points.size()), "setInputCloud") != PFT_OK) return;
-    check(pft_compute(handle_), "compute");
+    finish(check(pft_compute(handle_), "compute"));
   }
 
   // ---- auto_tracking.cpp:309-310, 270 ----
   StateT getResult() const {
     StateT r;
-    if (handle_) pft_get_result(handle_, &r);
+    if (handle_) check(pft_get_result(handle_, &r), "getResult");  // also reports device-side failures of the frame
     return r;
   }
   Affine3f toEigenMatrix(const StateT& particle) const {
@@ -300,6 +312,11 @@ class ParticleFilterTracker {
                    handle_ ? pft_last_error_string(handle_) : "");
     return st;
   }
+  void finish(int st) {
+    if (!throw_on_failure_) return;
+    if (st == PFT_OK) st = check(pft_synchronize(handle_), "compute");
+    if (st != PFT_OK) throw st;
+  }
   bool ensure() {
     if (handle_) return true;
     int st = pft_create(&cfg_, &handle_);
@@ -319,6 +336,7 @@ class ParticleFilterTracker {
   PointCloudInConstPtr ref_, input_;
   const pft_point_xyzrgba* dev_input_ = nullptr;
   size_t dev_n_ = 0;
+  bool throw_on_failure_ = false;
   CoherencePtr coherence_;
 };
 
