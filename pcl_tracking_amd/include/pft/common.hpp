@@ -5,8 +5,8 @@
 //   pcl::transformPointCloud<PointT>        common/impl/transforms.hpp /root/reference/src/auto_tracking.cpp:316, :668
 //
 // Plain loops over a few thousand model points, once per object (re-centring) and once per frame and object (the
-// moved model whose centroid the node publishes): host code in the reference, host code here.  The oracle restates
-// both (oracle/pft_oracle_app.c) and tests/test_cpp_host.py compares the C++ driver with it bit for bit.
+// moved model whose centroid the node publishes): host code in the reference, host code here.  The CPU checker under
+// oracle/ restates both, and tests/test_cpp_host.py compares the C++ driver with it bit for bit.
 #pragma once
 #include <cmath>
 
