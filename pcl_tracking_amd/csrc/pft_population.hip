@@ -387,6 +387,9 @@ __global__ void k_alias_materialize(const pft_particle* __restrict__ P, AliasVie
 void pftk_population(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n, int from_partials,
                      int do_normalize, int do_mean, int do_alias) {
   if (!n) return;
+  // one particle per thread over G workgroups until G would exceed 256 (the sums are the same adjacent-pair trees for
+  // any K and G).  One workgroup with K particles per thread and no device-scope barrier was tried for the reference's
+  // own 400-500 particles: slower (the two workgroups' barriers cost less than a second particle per thread).
   uint32_t K = 1;
   while ((n + PFT_POPC_THREADS * K - 1) / (PFT_POPC_THREADS * K) > PFT_POPM_MAX_WGS) K <<= 1;  // n <= PFT_MAX_PARTICLES: K <= 16
   uint32_t G = 1;

@@ -5,7 +5,7 @@
 TAG=${1:-r01}; ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof_$TAG; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-frontend > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
-for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES"; do
   n=$(echo $c | tr ' ' '_')
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$n -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-frontend > /dev/null 2> $OUT/pmc_$n.err
 done
@@ -24,8 +24,13 @@ avg = {k: sum(v[len(v)//2:]) / len(v[len(v)//2:]) for k, v in vals.items()}
 # bytes of wide coalesced reads -> doubled (upper bound for this gather-heavy kernel: other widths are uncalibrated)
 fetch = avg.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0
 write = avg.get("WRITE_SIZE", 0.0) * 1024.0
+valu, thr = avg.get("SQ_INSTS_VALU"), avg.get("SQ_THREAD_CYCLES_VALU")
 json.dump({"kernel": "k_likelihood<false>", "fetch_size_raw_kib": avg.get("FETCH_SIZE"), "write_size_raw_kib": avg.get("WRITE_SIZE"),
-           "hbm_bytes_per_launch": fetch + write, "tcc_hit": avg.get("TCC_HIT_sum"), "tcc_miss": avg.get("TCC_MISS_sum")},
+           "hbm_bytes_per_launch": fetch + write, "tcc_hit": avg.get("TCC_HIT_sum"), "tcc_miss": avg.get("TCC_MISS_sum"),
+           # VALU issue: wave-instructions per launch, and the share of the 64 lanes that were active in them
+           "valu_wave_insts_per_launch": valu, "salu_insts_per_launch": avg.get("SQ_INSTS_SALU"),
+           "lds_insts_per_launch": avg.get("SQ_INSTS_LDS"), "waves_per_launch": avg.get("SQ_WAVES"),
+           "valu_lane_utilisation": (thr / (64.0 * valu)) if valu and thr else None},
           open(os.path.join(out, "traffic_likelihood.json"), "w"), indent=1)
 print(open(os.path.join(out, "traffic_likelihood.json")).read())
 PY
