@@ -23,16 +23,21 @@
 // Algorithmic bytes per pair-eval: 16 (reference point) + 16 per candidate scanned in the reached leaf.
 #include "pft_device_utils.h"
 
+#ifndef PFT_LIK_PENALTY
+#define PFT_LIK_PENALTY 1
+#endif
+
 struct LikCtx {
   const uint32_t* words;   // LDS or HBM
   const float* tab;        // per-axis centre tables, stride per_axis
   uint32_t per_axis;
   const float* lut_h;      // [256] h/180
   const float* lut_s;      // [256] s/255
+  const float* pen;        // [256][8] by child mask: 0 for an existing child, +inf for an absent one
   const uint16_t* jump;    // LDS, or null
   int J;
   uint32_t lvlJ_start;
-  float margin, ominx, ominy, ominz, inv_res, ncell;
+  float margin, near_thr, ominx, ominy, ominz, inv_res, ncell;
   uint32_t leaf0;
   const uint16_t* leaf16;  // LDS: start offsets of the leaves (+ sentinel)
 };
@@ -152,9 +157,9 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         const float tx = (qx - cx.ominx) * cx.inv_res, ty = (qy - cx.ominy) * cx.inv_res,
                     tz = (qz - cx.ominz) * cx.inv_res;
         const float flx = floorf(tx), fly = floorf(ty), flz = floorf(tz);
-        // (bitwise &: no short-circuit branches)
-        const bool inside = (tx >= 0.0f) & (tx < cx.ncell) & (ty >= 0.0f) & (ty < cx.ncell) & (tz >= 0.0f) &
-                            (tz < cx.ncell);
+        // inside the box on all three axes: smallest coordinate >= 0 and largest < 2^D (two three-operand instructions and
+        // two compares instead of six compares)
+        const bool inside = (fminf(fminf(tx, ty), tz) >= 0.0f) & (fmaxf(fmaxf(tx, ty), tz) < cx.ncell);
         const float fx = tx - flx, fy = ty - fly, fz = tz - flz;
         const float mg = cx.margin, mh = 1.0f - cx.margin;
         const uint32_t kx = inside ? (uint32_t)flx : 0u, ky = inside ? (uint32_t)fly : 0u,
@@ -163,11 +168,18 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         // of 2^sh leaf cells has its low (high) face on an axis exactly at the query's leaf-cell face iff the low sh
         // key bits are all 0 (all 1): the levels concerned are sh <= V, V = max over the axes that are within
         // the margin of (trailing zeros | trailing ones) of the key.  Queries outside the box take no shortcut.
-        // (branch-free: v_ffbl_b32 returns -1 for a zero operand, which the unsigned minimum turns into the 31 wanted
-        // for key 0; keys never have all 32 bits set)
-        const int vx = near_face_level(kx, fx < mg, fx > mh), vy = near_face_level(ky, fy < mg, fy > mh),
-                  vz = near_face_level(kz, fz < mg, fz > mh);
-        const int V = inside ? max(vx, max(vy, vz)) : 31;
+        // Only 0.4 % of the queries are near a face at all: three waves out of four have none, and skip the per-axis
+        // evaluation on a (conservative, slightly wider) test of the largest distance from the cell centre.
+        int V = -1;
+        const float off = fmaxf(fmaxf(fabsf(fx - 0.5f), fabsf(fy - 0.5f)), fabsf(fz - 0.5f));
+        if (__builtin_amdgcn_ballot_w64(off > cx.near_thr)) {
+          // (branch-free: v_ffbl_b32 returns -1 for a zero operand, which the unsigned minimum turns into the 31 wanted
+          // for key 0; keys never have all 32 bits set)
+          const int vx = near_face_level(kx, fx < mg, fx > mh), vy = near_face_level(ky, fy < mg, fy > mh),
+                    vz = near_face_level(kz, fz < mg, fz > mh);
+          V = max(vx, max(vy, vz));
+        }
+        V = inside ? V : 31;
         const int lim = min(D, D - 1 - V);  // fast levels are those with lvl < lim
         if (cx.J > 0) {  // (wave-uniform) the jump lands on level J: its cell spans 2^(D-J) leaf cells, D-J > V
           const int sh = D - cx.J;
@@ -221,8 +233,29 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         float dx0 = cx0 - qx, dx1 = cx1 - qx, dy0 = cy0 - qy, dy1 = cy1 - qy, dz0 = cz0 - qz, dz1 = cz1 - qz;
         float X0 = dx0 * dx0, X1 = dx1 * dx1, Y0 = dy0 * dy0, Y1 = dy1 * dy1, Z0 = dz0 * dz0, Z1 = dz1 * dz1;
         const float yz[4] = {Y0 + Z0, Y0 + Z1, Y1 + Z0, Y1 + Z1};
-        // (a tournament over integer keys -- absent children as all-ones, strict comparisons from the right -- needs 36
-        // instructions instead of these 48 and measured 2 % SLOWER: 209.6 against 204.9 us)
+#if PFT_LIK_PENALTY
+        // "if (dist >= min) continue" over the existing children in ascending order = the lowest index among the minima.
+        // Absent children are priced out by ADDING +inf (d + 0.0f is d exactly): the eight penalties of the node's mask
+        // come from LDS in two 16-byte reads, which replaces a bit test per child (and + compare: 54 cycles per level) by
+        // an add (21).  Then the minimum (v_min3 tree) and the first index that attains it.
+        const float4 pa = *reinterpret_cast<const float4*>(cx.pen + 8u * mask);
+        const float4 pb = *reinterpret_cast<const float4*>(cx.pen + 8u * mask + 4u);
+        const float d0 = (X0 + yz[0]) + pa.x, d1 = (X0 + yz[1]) + pa.y, d2 = (X0 + yz[2]) + pa.z, d3 = (X0 + yz[3]) + pa.w;
+        const float d4 = (X1 + yz[0]) + pb.x, d5 = (X1 + yz[1]) + pb.y, d6 = (X1 + yz[2]) + pb.z, d7 = (X1 + yz[3]) + pb.w;
+        float m0, m1, m2, best;
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m0) : "v"(d0), "v"(d1), "v"(d2));
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m1) : "v"(d3), "v"(d4), "v"(d5));
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m2) : "v"(d6), "v"(d7), "v"(m0));
+        asm("v_min_f32 %0, %1, %2" : "=v"(best) : "v"(m1), "v"(m2));
+        uint32_t bc = 7u;
+        bc = d6 == best ? 6u : bc;
+        bc = d5 == best ? 5u : bc;
+        bc = d4 == best ? 4u : bc;
+        bc = d3 == best ? 3u : bc;
+        bc = d2 == best ? 2u : bc;
+        bc = d1 == best ? 1u : bc;
+        bc = d0 == best ? 0u : bc;
+#else
         float best = INFINITY;
         uint32_t bc = 0;
 #pragma unroll
@@ -234,6 +267,7 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
             bc = c;
           }
         }
+#endif
         if (DEBUG_NN) {  // "hard" step: the per-axis nearest child (the ideal corner) does not exist
           const uint32_t ideal = ((X1 < X0) ? 4u : 0u) | ((Y1 < Y0) ? 2u : 0u) | ((Z1 < Z0) ? 1u : 0u);
           if (!((mask >> ideal) & 1u)) dbg_hard++;
@@ -386,10 +420,12 @@ __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * 
   int J = fast ? hdr->jump_level : 0;
 
   // LDS carve: luts (2 KiB) | centre tables | jump table | node words
-  float* lut_h = reinterpret_cast<float*>(smem);
+  float* pen = reinterpret_cast<float*>(smem);
+  constexpr uint32_t pen_bytes = PFT_LIK_PENALTY ? 256u * 8u * 4u : 0u;
+  float* lut_h = reinterpret_cast<float*>(smem + pen_bytes);
   float* lut_s = lut_h + 256;
   float* tab = lut_s + 256;
-  uint32_t used = 2048u + 3u * per_axis * 4u;
+  uint32_t used = pen_bytes + 2048u + 3u * per_axis * 4u;
   used = (used + 15u) & ~15u;
   // node words: branch levels as u32; the leaf level (about 70 % of the words) as u16 start offsets when the
   // cropped cloud has fewer than 65536 points
@@ -420,6 +456,8 @@ __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * 
     lut_h[i] = (float)i / 180.0f;
     lut_s[i] = (float)i / 255.0f;
   }
+  if (PFT_LIK_PENALTY)
+    for (uint32_t i = threadIdx.x; i < 2048u; i += blockDim.x) pen[i] = ((i >> 3) >> (i & 7u)) & 1u ? 0.0f : INFINITY;
   // per-level per-axis voxel-centre tables, centre(level l, key k) = (float)((k + 0.5) * res * 2^(D-l) + min) exactly as
   // genVoxelCenterFromOctreeKey; entry 2^l - 2 + k.  Formed here, a few entries per thread, instead of by the one
   // workgroup of the builder (4.6 us there) and a global round trip.
@@ -455,10 +493,13 @@ __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * 
   cx.per_axis = per_axis;
   cx.lut_h = lut_h;
   cx.lut_s = lut_s;
+  cx.pen = pen;
   cx.jump = ljump;
   cx.J = J;
   cx.lvlJ_start = J > 0 ? hdr->lvl_start[J] : 0u;
   cx.margin = hdr->margin_cells;
+  // |f - 0.5| above this: the query may be within `margin` of a face of its leaf cell (a little wider than the exact test)
+  cx.near_thr = 0.5f - 1.01f * hdr->margin_cells - 1.0e-6f;
   cx.ominx = hdr->ominf[0];
   cx.ominy = hdr->ominf[1];
   cx.ominz = hdr->ominf[2];
