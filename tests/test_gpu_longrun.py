@@ -8,11 +8,13 @@ particle arrays, the resample epochs, the one-pass crop's launch tags and (KLD v
 changes every resample.
 
 Two comparisons per configuration:
-  * SAME TRIG  -- the oracle forms pose -> matrix with double sin / cos rounded to float, exactly as the device
-    does (oracle.Tracker.set_trig_mode(1), a test-only switch; PCL's cosf / sinf stays the oracle's default).
-    Both sides then see identical matrices and identical Philox draws; what is left are the documented
-    re-associated double sums (per-particle likelihood sum, weight sum, weighted mean: <= 1 ulp(float) each), so
-    every frame must agree to a few ulp and the particle sets must be the same sets.
+  * SAME ARITHMETIC -- the oracle in its two test-only modes: pose -> matrix with double sin / cos rounded to float
+    (set_trig_mode(1); PCL's cosf / sinf stays the default) and the weight sum / weighted mean in the adjacent-pair
+    tree order the product specifies for its parallel reductions (set_sum_mode(1); PCL's sequential sums stay the
+    default).  Both sides then see identical matrices, identical Philox draws and identical sums: every frame must be
+    BIT-IDENTICAL -- result pose, every particle, every weight, the KLD particle count.  (With PCL's sums the runs
+    part after a few frames: the mean re-enters the population through slot 0 of the resample, and PCL's Walker alias
+    table is a discontinuous function of the weights -- DESIGN.md section 4.)
   * OWN TRIG   -- each side with its own sin / cos (glibc cosf / sinf against the device's double -> float): the
     north_star bar of 1e-4 on the weighted-mean pose; the first frame at which 1e-4 is exceeded is reported
     (DESIGN.md section 4 records it).
@@ -93,27 +95,22 @@ def test_long_run_same_trig_is_bit_stable(gpu, orc, P, kld):
         pg, po = g.getParticles(), o.get_particles()
         # KLD variant: the particle count of every frame is the oracle's
         assert len(pg) == len(po), (f, len(pg), len(po))
-        # the weighted mean is a double tree sum on the device and a sequential float sum in PCL (DESIGN.md
-        # "numerics": ~1e-7), on top of weights that may differ in their last digits
         a = max(abs(float(rg[k]) - float(ro[k])) for k in KEYS)
-        assert a <= 1e-6, (f, a, rg, ro)
+        # identical matrices, identical Philox draws, identical summation order: nothing is left to differ
+        assert rg.tobytes() == ro.tobytes(), (f, a, rg, ro)
         if a > worst_pose:
             worst_pose, worst_frame = a, f
         assert rg["weight"] == ro["weight"]
-        # particle set: the same draws from the same alias entries.  Poses bit-equal (Box-Muller in double on both
-        # sides; ocml and glibc agree except for rare 1-ulp(double) cases that survive the cast to float).  A raw
-        # weight may differ by 1 ulp (re-associated double sum); when that particle is the minimum or maximum, every
-        # normalised weight moves by ~1e-5 relative, and an alias draw within that distance of its threshold picks
-        # the other entry: such a particle is counted, not tolerated silently
+        # particle set: the same draws from the same alias entries, the same Box-Muller noise (double on both sides:
+        # ocml and glibc could differ in a last bit that survives the cast to float -- it has not happened in these
+        # runs); the per-particle likelihood sums are re-associated, but agree after the cast to float
         dk = np.zeros(len(pg), np.int64)
         for k in KEYS:
             dk = np.maximum(dk, ulp_diff(pg[k], po[k]))
-        n_off = int((dk > 1).sum())
+        n_off = int((dk > 0).sum())
         flipped += n_off
-        assert n_off <= max(1, len(pg) // 2000), (f, n_off)
-        assert (dk == 0).mean() >= 0.998, (f, float((dk == 0).mean()))
-        same = dk <= 1
-        np.testing.assert_allclose(pg["weight"][same], po["weight"][same], rtol=2e-4, atol=1e-12, err_msg="frame %d" % f)
+        assert n_off == 0, (f, n_off, int(dk.max()))
+        np.testing.assert_array_equal(pg["weight"].view(np.uint32), po["weight"].view(np.uint32), err_msg="frame %d" % f)
     # the run really did cross the builder threshold in both directions, and the depth changed on the way
     big = [c > 18000 for c in crops]
     assert any(big) and not all(big), crops
