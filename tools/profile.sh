@@ -1,13 +1,13 @@
 #!/bin/bash
 # Produces the artefacts kept under profiles/: rocprofv3 kernel-trace stats of the bench command, and the
 # HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs) for the dominant kernel.
-# usage (GPU box, repo root): bash tools/profile.sh <tag>      -> gpurun_out/prof_<tag>/
-TAG=${1:-r01}; ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof_$TAG; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-frontend > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+# usage (GPU box, repo root): bash tools/profile.sh <tag> [bench.py arguments of another configuration]  -> gpurun_out/prof_<tag>/
+TAG=${1:-r01}; shift; ARGS="$*"; ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof_$TAG; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-frontend $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES"; do
   n=$(echo $c | tr ' ' '_')
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$n -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-frontend > /dev/null 2> $OUT/pmc_$n.err
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$n -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-frontend $ARGS > /dev/null 2> $OUT/pmc_$n.err
 done
 cd $ROOT
 python3 tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt
