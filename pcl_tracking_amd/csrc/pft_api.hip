@@ -43,6 +43,7 @@ struct pft_tracker {
   pft_point_xyzrgba* d_in_raw = nullptr;
   float4* d_in_pts = nullptr;
   uint32_t in_cap = 0, N = 0;
+  const pft_point_xyzrgba* raw_pending = nullptr;  // input handed over but not yet packed: the next crop does it
   pft_particle* d_part[2] = {nullptr, nullptr};
   int cur = 0;
   float* d_mats = nullptr;
@@ -676,12 +677,11 @@ static int set_input_common(pft_tracker* t, const void* src, size_t n, bool devi
       HIPCHK(t, hipMemcpyAsync(t->d_in_raw, src, n * sizeof(pft_point_xyzrgba), hipMemcpyHostToDevice, t->stream));
       dsrc = t->d_in_raw;
     }
-    {
-      ProfScope ps(t, PFT_K_PACK);
-      pftk_pack_input(t->stream, dsrc, (uint32_t)n, t->d_in_pts);
-    }
+    // the 16-byte records (d_in_pts) are formed by the first crop of the frame, which reads the 32-byte layout
+    t->raw_pending = dsrc;
     if (!device) HIPCHK(t, hipStreamSynchronize(t->stream));  // the host buffer is only borrowed for this call
   }
+  if (!n) t->raw_pending = nullptr;
   t->has_input = n > 0;
   sync_dev(t);
   return PFT_OK;
@@ -735,7 +735,8 @@ static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32
   {
     ProfScope ps(t, PFT_K_CROP);
     if (++t->crop_epoch == 0) t->crop_epoch = 1;
-    pftk_crop(t->stream, t->prm, d, bbox_from_partials, t->crop_epoch);
+    pftk_crop(t->stream, t->prm, d, bbox_from_partials, t->crop_epoch, t->raw_pending);
+    t->raw_pending = nullptr;
     if (t->inject_error) {  // test hook: what a failing crop / builder would leave behind
       hipLaunchKernelGGL(k_inject_error, dim3(1), dim3(1), 0, t->stream, t->d_hdr, t->inject_error);
       t->inject_error = 0;

@@ -164,6 +164,19 @@ __device__ __forceinline__ void particle_sample(pft_particle& q, const PftParams
   q.yaw += (float)(z[5] * sigma[5] + mean[5]);
 }
 
+// Correctly rounded float square root for DistanceCoherence's Vector4f::norm(): the hardware estimate (1 ulp) and the
+// round-to-nearest correction of the compiler's own sqrtf expansion, WITHOUT that expansion's rescaling of arguments
+// below 2^-96 (six instructions in the likelihood's inner loop): v_sqrt_f32 flushes such an argument to 0, and the only
+// consumer here is 1.0 + d*d*w in double, which is 1.0 for every d below 2^-27 / sqrt(w) whatever its last bits.
+__device__ __forceinline__ float sqrt_rn_coherence(float x) {
+  float s = __builtin_amdgcn_sqrtf(x);
+  const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+  const float ed = fmaf(-sd, s, x), eu = fmaf(-su, s, x);
+  s = ed <= 0.0f ? sd : s;
+  s = eu > 0.0f ? su : s;
+  return s;
+}
+
 // A1  pcl::getTransformation (common/impl/eigen.hpp): R = Rz(yaw) Ry(pitch) Rx(roll).
 // sin/cos evaluated in double and rounded to float (PCL calls cosf/sinf; both are within 1 ulp).
 __device__ __forceinline__ void pose_to_matrix(const pft_particle& q, float* m /*12*/) {

@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256) void k_likelihood_exact(PftParams prm, PftDev 
         // DistanceCoherence x HSVColorCoherence: as in pft_likelihood.hip (A7a, A7b)
         const float ex = qx - bt.x, ey = qy - bt.y, ez = qz - bt.z;
         const float n2 = (ex * ex + ey * ey) + ez * ez;
-        const double dist = (double)sqrtf(n2);
+        const double dist = (double)sqrt_rn_coherence(n2);
         const double A = 1.0 + dist * dist * wd;
         const float4 rh = d.ref_hsv[j];
         const uint32_t pk = __float_as_uint(bt.w);

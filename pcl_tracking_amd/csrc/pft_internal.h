@@ -186,7 +186,9 @@ void pftk_likelihood_exact(hipStream_t s, const PftParams& p, const PftDev& d, u
 void pftk_resample_kld(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t epoch, pft_particle* out,
                        const int32_t* table_a, const double* table_q, int32_t* bins_out);
 // epoch: a value that differs from the handle's previous crop launch (non-zero); tags the per-workgroup counts of the one-pass crop
-void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d, bool bbox_from_partials, uint32_t epoch);
+// raw: the input in PCL's 32-byte layout when its 16-byte records have not been formed yet (first crop of a frame), else null
+void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d, bool bbox_from_partials, uint32_t epoch,
+               const pft_point_xyzrgba* raw);
 void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t expected_points);
 // no-op launch unless the sorted builder flagged "radix passes too few" (error bit 3): then the single-workgroup build
 void pftk_octree_rescue(hipStream_t s, const PftParams& p, const PftDev& d);

@@ -107,6 +107,89 @@ __global__ void k_resample(PftParams p, const pft_particle* __restrict__ old, Al
   }
 }
 
+// The same resample with FOUR lanes per particle (the product path; k_resample<TABLE> above stays for the explicit-table
+// test hook).  One lane's chain -- two binary searches, Philox, three Box-Muller pairs (log, sqrt, sin, cos in double),
+// six more double sin / cos for the matrix -- is 7 us of pure latency for 8 192 particles; its pieces are independent:
+//   lane 0 of a quad: the alias draw and the gather of the drawn particle
+//   lanes 1..3:       one normal pair each (Philox slot = the lane's role)          -- concurrently with lane 0
+//   then lanes 1..3:  cos / sin of roll / pitch / yaw of the new pose               -- concurrently
+//   lane 0:           the nine matrix products, the stores
+// Every number is formed by the same operations as in the one-lane kernel: bit-identical results.
+__global__ __launch_bounds__(256) void k_resample4(PftParams p, const pft_particle* __restrict__ old, AliasView v,
+                                                   const PftHeader* __restrict__ hdr, uint32_t epoch,
+                                                   pft_particle* __restrict__ out, float* __restrict__ mats) {
+  __shared__ double cD[256], cE[256];
+  v.m = hdr->alias_m;
+  v.nh = hdr->alias_nh;
+  v.sD = (v.m + 255u) / 256u;
+  v.sE = (v.nh + 255u) / 256u;
+  {
+    const uint32_t t = threadIdx.x;
+    if (v.m && t * v.sD < v.m) cD[t] = v.D[min((t + 1u) * v.sD, v.m) - 1u];
+    if (v.nh && t * v.sE < v.nh) cE[t] = v.E[min((t + 1u) * v.sE, v.nh) - 1u];
+  }
+  __syncthreads();
+  v.cD = cD;
+  v.cE = cE;
+  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t li = gt >> 2, role = gt & 3u;
+  const int lane = lane_id(), q0 = lane & ~3;  // first lane of my quad
+  const bool live = li < p.P_local;
+  const uint32_t g = p.id_offset + li;
+  pft_particle s = {0, 0, 0, 1.0f, 0, 0, 0, 0};
+  double z0 = 0.0, z1 = 0.0;
+  if (live) {
+    if (role == 0u) {
+      if (g == 0) {
+        s = hdr->rep;
+      } else {
+        uint32_t o[4];
+        philox4x32(g, 0, epoch, 1, p.seed_lo, p.seed_hi, o);
+        double rU = u53(o[0], o[1]) * (double)p.P_total;
+        const int k = (int)rU;
+        rU -= k;
+        int32_t a_large;
+        const double qk = alias_q(v, (uint32_t)k, old[k].weight, &a_large);
+        int target;
+        if (rU < qk)
+          target = k;
+        else
+          target = (v.pos[k] >> 31) ? a_large : alias_a_small(v, (uint32_t)k);
+        s = old[target];
+      }
+    } else if (g != 0) {
+      normal_pair(p, g, role, epoch, 1, z0, z1);
+    }
+  }
+  // the step noise of ParticleXYZRPY::sample: component += (float)(z * sigma + mean), mean = 0; role r holds the pair of
+  // components 2r - 2, 2r - 1 (x y | z roll | pitch yaw)
+  const float n0 = (role && g != 0) ? (float)(z0 * p.step_sigma[2u * role - 2u] + 0.0) : 0.0f;
+  const float n1 = (role && g != 0) ? (float)(z1 * p.step_sigma[2u * role - 1u] + 0.0) : 0.0f;
+  const float nx = __shfl(n0, q0 + 1), ny = __shfl(n1, q0 + 1), nz = __shfl(n0, q0 + 2), nroll = __shfl(n1, q0 + 2),
+              npitch = __shfl(n0, q0 + 3), nyaw = __shfl(n1, q0 + 3);
+  if (role == 0u && g != 0) {  // (slot 0 of the population is the representative state verbatim: no noise)
+    s.x += nx; s.y += ny; s.z += nz;
+    s.roll += nroll; s.pitch += npitch; s.yaw += nyaw;
+  }
+  // A1: lanes 1..3 take one angle each (double cos / sin rounded to float, as pose_to_matrix)
+  const float roll = __shfl(s.roll, q0), pitch = __shfl(s.pitch, q0), yaw = __shfl(s.yaw, q0);
+  const float ang = role == 1u ? roll : (role == 2u ? pitch : yaw);
+  const float ca = (float)cos((double)ang), sa = (float)sin((double)ang);
+  const float E = __shfl(ca, q0 + 1), F = __shfl(sa, q0 + 1), C = __shfl(ca, q0 + 2), D = __shfl(sa, q0 + 2),
+              A = __shfl(ca, q0 + 3), B = __shfl(sa, q0 + 3);
+  if (live && role == 0u) {
+    out[li] = s;
+    if (mats) {
+      const float DE = D * E, DF = D * F;
+      float m[12];
+      m[0] = A * C;  m[1] = A * DF - B * E;  m[2] = B * F + A * DE;  m[3] = s.x;
+      m[4] = B * C;  m[5] = A * E + B * DF;  m[6] = B * DE - A * F;  m[7] = s.y;
+      m[8] = -D;     m[9] = C * F;           m[10] = C * E;          m[11] = s.z;
+      store_matrix(mats, li, m);
+    }
+  }
+}
+
 __global__ void k_pose_to_matrix(const pft_particle* __restrict__ p, uint32_t n, float* __restrict__ mats) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -301,13 +384,16 @@ __global__ __launch_bounds__(1024) void k_crop_scatter(const float4* __restrict_
 // publishes (launch epoch << 32 | count) with an atomic, and one wave collects the counts of its predecessors with
 // atomic loads, spinning on the few that are not there yet (bounded: a failure raises the error flag instead of
 // hanging).  50 000 points are 49 workgroups, so the chain is one step deep in practice.
+// raw != null (the first crop after pft_set_input*): the points are read in PCL's 32-byte layout and their 16-byte
+// records are written to `packed` on the way, for the frame's later crops (fuses k_pack_input: one launch less per frame)
 template <bool FROM_PART>
 __global__ __launch_bounds__(1024) void k_crop_onepass(const float4* __restrict__ in, uint32_t N,
                                                        const float* __restrict__ bbox6, const float* __restrict__ part,
                                                        uint32_t nparts, unsigned long long* __restrict__ slots,
                                                        uint32_t epoch, int argorder, float4* __restrict__ out,
                                                        int32_t* __restrict__ out_idx, PftHeader* __restrict__ hdr,
-                                                       uint32_t* host_stat) {
+                                                       uint32_t* host_stat, const pft_point_xyzrgba* __restrict__ raw,
+                                                       float4* __restrict__ packed) {
   __shared__ uint32_t s_scan[20];
   __shared__ uint32_t s_base, s_b;
   __shared__ float s6[6];
@@ -328,7 +414,14 @@ __global__ __launch_bounds__(1024) void k_crop_onepass(const float4* __restrict_
   bool keep = false;
   float4 p = make_float4(0, 0, 0, 0);
   if (i < N) {
-    p = in[i];
+    if (raw) {
+      const float4* src = reinterpret_cast<const float4*>(raw + i);
+      const float4 a = src[0], c = src[1];
+      p = make_float4(a.x, a.y, a.z, c.x);  // c.x carries the rgba bits
+      packed[i] = p;
+    } else {
+      p = in[i];
+    }
     keep = crop_keep(p, s6);
   }
   uint32_t total;
@@ -435,9 +528,14 @@ static AliasView alias_view(const PftDev& d, uint32_t n) {
   return v;
 }
 void pftk_resample(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t epoch, pft_particle* out) {
-  hipLaunchKernelGGL(k_resample<false>, dim3(cdiv(p.P_local, 256)), dim3(256), 0, s, p, d.part_all,
-                     alias_view(d, p.P_total), (const int32_t*)nullptr, (const double*)nullptr, d.hdr, epoch, out,
-                     d.mats);
+  static const bool one_lane = getenv("PFT_RESAMPLE_ONE_LANE") != nullptr;  // A/B and cross-check: the one-lane-per-particle kernel
+  if (one_lane)
+    hipLaunchKernelGGL(k_resample<false>, dim3(cdiv(p.P_local, 256)), dim3(256), 0, s, p, d.part_all,
+                       alias_view(d, p.P_total), (const int32_t*)nullptr, (const double*)nullptr, d.hdr, epoch, out,
+                       d.mats);
+  else
+    hipLaunchKernelGGL(k_resample4, dim3(cdiv(4u * p.P_local, 256)), dim3(256), 0, s, p, d.part_all,
+                       alias_view(d, p.P_total), d.hdr, epoch, out, d.mats);
 }
 void pftk_resample_table(hipStream_t s, const PftParams& p, const pft_particle* old, const int32_t* a,
                          const double* q, const PftHeader* hdr, uint32_t epoch, pft_particle* out) {
@@ -463,18 +561,21 @@ void pftk_aabb(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_pa
                      lds_points, d.p_active);
   if (finalize) hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(512), 0, s, d.bbox_part, d.bbox_grid, d.bbox6);
 }
-void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d, bool from_part, uint32_t epoch) {
+void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d, bool from_part, uint32_t epoch,
+               const pft_point_xyzrgba* raw) {
   uint32_t nb = cdiv(d.N ? d.N : 1, 1024);
   const bool two_pass = getenv("PFT_CROP_TWO_PASS") != nullptr;  // A/B timing and cross-check (read per call: tests toggle it)
+  float4* packed = const_cast<float4*>(d.in_pts);
   if (!two_pass) {
     if (from_part)
       hipLaunchKernelGGL(k_crop_onepass<true>, dim3(nb), dim3(1024), 0, s, d.in_pts, d.N, d.bbox6, d.bbox_part, d.bbox_grid,
-                         d.crop_slots, epoch, p.hsv_argorder, d.crop_pts, d.crop_idx, d.hdr, d.host_stat);
+                         d.crop_slots, epoch, p.hsv_argorder, d.crop_pts, d.crop_idx, d.hdr, d.host_stat, raw, packed);
     else
       hipLaunchKernelGGL(k_crop_onepass<false>, dim3(nb), dim3(1024), 0, s, d.in_pts, d.N, d.bbox6, d.bbox_part, d.bbox_grid,
-                         d.crop_slots, epoch, p.hsv_argorder, d.crop_pts, d.crop_idx, d.hdr, d.host_stat);
+                         d.crop_slots, epoch, p.hsv_argorder, d.crop_pts, d.crop_idx, d.hdr, d.host_stat, raw, packed);
     return;
   }
+  if (raw) pftk_pack_input(s, raw, d.N, packed);  // the two-pass kernels read the 16-byte records
   if (from_part) {
     hipLaunchKernelGGL(k_crop_count<true>, dim3(nb), dim3(1024), 0, s, d.in_pts, d.N, d.bbox6, d.bbox_part,
                        d.bbox_grid, d.crop_counts);

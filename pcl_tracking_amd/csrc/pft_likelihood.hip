@@ -353,7 +353,7 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         // DistanceCoherence: Vector4f norm (SSE3 packet reduction (dx2+dy2)+(dz2+0)); 1/(1 + d*d*w)
         float ex = qx - bt.x, ey = qy - bt.y, ez = qz - bt.z;
         float n2 = (ex * ex + ey * ey) + ez * ez;
-        double dist = (double)sqrtf(n2);
+        double dist = (double)sqrt_rn_coherence(n2);
         double A = 1.0 + dist * dist * wd;
         // HSVColorCoherence on precomputed (h,s,v): 1/(1 + w * diff2)
         const float4 rh = d.ref_hsv[j];
