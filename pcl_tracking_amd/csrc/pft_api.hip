@@ -786,11 +786,6 @@ static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32
   }
 }
 
-__global__ void k_copy_particles(const pft_particle* __restrict__ src, pft_particle* __restrict__ dst, uint32_t n) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = src[i];
-}
-
 static int check_ready(pft_tracker* t) {
   if (!t) return PFT_ERR_INVALID_ARG;
   hipSetDevice(t->cfg.device_id);
@@ -869,9 +864,8 @@ extern "C" int pft_dist_phase_b(pft_tracker* t) {
   stage_crop_octree_likelihood(t, t->dev, t->prm.P_local, false, false);
   {
     ProfScope ps(t, PFT_K_POPULATION);
-    pftk_finalize_raw(t->stream, t->prm, t->dev, t->prm.P_local, nullptr);
-    hipLaunchKernelGGL(k_copy_particles, dim3((t->prm.P_local + 255) / 256), dim3(256), 0, t->stream,
-                       t->d_part[t->cur], static_cast<pft_particle*>(t->bound_shard), t->prm.P_local);
+    // raw weights from the partial sums, written with their particles straight into the all-gather's send buffer
+    pftk_finalize_raw(t->stream, t->prm, t->dev, t->prm.P_local, nullptr, static_cast<pft_particle*>(t->bound_shard));
   }
   return PFT_OK;
 }
@@ -1087,7 +1081,7 @@ extern "C" int pft_eval_weights(pft_tracker* t, const pft_particle* particles, s
   pftk_pose_to_matrix(t->stream, t->d_dbg_part, (uint32_t)P, t->d_mats);
   stage_aabb(t, d, (uint32_t)P, false);
   stage_crop_octree_likelihood(t, d, (uint32_t)P, want_nn, true, true);
-  pftk_finalize_raw(t->stream, t->prm, d, (uint32_t)P, t->d_dbg_f);
+  pftk_finalize_raw(t->stream, t->prm, d, (uint32_t)P, t->d_dbg_f, nullptr);
   if (raw_w) HIPCHK(t, hipMemcpyAsync(raw_w, t->d_dbg_f, P * sizeof(float), hipMemcpyDeviceToHost, t->stream));
   if (nn_idx) HIPCHK(t, hipMemcpyAsync(nn_idx, t->d_nn_idx, pairs * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
   if (nn_d2) HIPCHK(t, hipMemcpyAsync(nn_d2, t->d_nn_d2, pairs * sizeof(float), hipMemcpyDeviceToHost, t->stream));

@@ -205,8 +205,9 @@ void pftk_octree_sorted(hipStream_t s, const PftParams& p, const PftDev& d, cons
                         int npass);
 void pftk_likelihood(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, bool debug_nn,
                      int num_cus);
+// shard (nullable): sharded handles -- the particles with their raw weights also go into the all-gather's send buffer
 void pftk_finalize_raw(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles,
-                       float* raw_out /*nullable*/);
+                       float* raw_out /*nullable*/, pft_particle* shard /*nullable*/);
 // normalise + update + alias prefix form over part_all[0..n) in one launch; from_partials != 0: the raw weights are
 // first formed from the likelihood partial sums (single-GPU path: fuses k_finalize_raw)
 void pftk_population(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n, int from_partials,

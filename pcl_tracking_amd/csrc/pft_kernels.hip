@@ -465,10 +465,11 @@ __global__ __launch_bounds__(1024) void k_crop_onepass(const float4* __restrict_
   }
 }
 
-// raw weight of a particle: w = -(float) val  (ApproxNearestPairPointCloudCoherence::computeCoherence)
+// raw weight of a particle: w = -(float) val  (ApproxNearestPairPointCloudCoherence::computeCoherence).
+// shard != null (sharded handles): the particle with its raw weight also goes into the exchange buffer the all-gather reads
 __global__ void k_finalize_raw(const double* __restrict__ partial, uint32_t nchunk, uint32_t n,
                                pft_particle* __restrict__ part, float* __restrict__ raw_out,
-                               const uint32_t* __restrict__ p_active) {
+                               const uint32_t* __restrict__ p_active, pft_particle* __restrict__ shard) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (p_active) n = *p_active;  // KLD variant: particle_num_ lives on the device
   if (i >= n) return;
@@ -477,6 +478,11 @@ __global__ void k_finalize_raw(const double* __restrict__ partial, uint32_t nchu
   float w = -(float)v;
   part[i].weight = w;
   if (raw_out) raw_out[i] = w;
+  if (shard) {
+    pft_particle q = part[i];
+    q.weight = w;
+    shard[i] = q;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -588,8 +594,9 @@ void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d, bool from_par
                        d.bbox_grid, d.crop_counts, p.hsv_argorder, d.crop_pts, d.crop_idx, d.hdr, d.host_stat);
   }
 }
-void pftk_finalize_raw(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, float* raw_out) {
+void pftk_finalize_raw(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, float* raw_out,
+                       pft_particle* shard) {
   if (!n_particles) return;
   hipLaunchKernelGGL(k_finalize_raw, dim3(cdiv(n_particles, 256)), dim3(256), 0, s, d.partial, p.nchunk, n_particles,
-                     d.part_cur, raw_out, d.p_active);
+                     d.part_cur, raw_out, d.p_active, shard);
 }

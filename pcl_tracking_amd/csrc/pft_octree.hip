@@ -96,7 +96,7 @@ __device__ __forceinline__ bool box_violates(float x, float y, float z, const do
 // ballot per event, no workgroup barrier); (b) the workgroup then looks for later violators with a per-thread AABB
 // quick reject; each remaining event costs one min-index reduction.
 #define PFT_REPLAY_HEAD 1024u
-__device__ __forceinline__ void box_replay(BuildSh& S, const float4* __restrict__ pts, uint32_t n, double res) {
+__device__ __forceinline__ void box_replay(BuildSh& S, const float4* __restrict__ pts, uint32_t n, double res, unsigned long long* hdr_ticks) {
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   const uint32_t head = n < PFT_REPLAY_HEAD ? n : PFT_REPLAY_HEAD;
   // (b), first half: thread-local AABB of the thread's strided points after the head -- done by the waves that have
@@ -117,6 +117,7 @@ __device__ __forceinline__ void box_replay(BuildSh& S, const float4* __restrict_
     }
   };
   if (tid >= WAVE) local_aabb();
+  if (tid == WAVE) hdr_ticks[13] = wall_clock64();
   if (tid < WAVE) {
     float4 q[PFT_REPLAY_HEAD / WAVE];
 #pragma unroll
@@ -183,6 +184,7 @@ __device__ __forceinline__ void box_replay(BuildSh& S, const float4* __restrict_
       S.err = err;
     }
     if (tid == 0) S.cur = head;
+    if (tid == 0) hdr_ticks[14] = wall_clock64();
   }
   __syncthreads();
   if (S.err || n <= PFT_REPLAY_HEAD) return;
@@ -628,7 +630,7 @@ __global__ __launch_bounds__(PFT_BUILD_THREADS) void k_octree_build(PftParams pr
   uint32_t leaf_start = 0, n_leaves = 0;
   int path = 0;
   if (n > 0) {
-    box_replay(S, d.crop_pts, n, prm.res);
+    box_replay(S, d.crop_pts, n, prm.res, d.hdr->ticks);
     __syncthreads();
     STAMP(1);
   }

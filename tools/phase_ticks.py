@@ -25,6 +25,7 @@ t._check(t._L.pft_debug_get_ticks(t._h, tk.ctypes.data_as(C.c_void_p)))
 o = tk[:9].astype(np.int64)
 names = ["init", "replay", "keys", "levels", "leaf-count+scan", "leaf-scatter", "leaf-rank+gather", "flush", "tables"]
 print("octree phases (us):", dict(zip(names[1:], ((o[1:] - o[:-1]) / 100.0).round(2))), "total", (o[8] - o[0]) / 100.0)
+print("  replay split (us): start->tail-aabb done %.2f, start->head done %.2f, whole replay %.2f" % ((int(tk[13]) - int(tk[0])) / 100.0, (int(tk[14]) - int(tk[0])) / 100.0, (int(tk[1]) - int(tk[0])) / 100.0))
 print("  levels split (us): point pass %.2f  count %.2f  scan %.2f  write+zero %.2f" % tuple(tk[9:13].astype(np.float64) / 100.0))
 p = tk[16:22].astype(np.int64)
 names = ["load", "normalize", "mean", "alias-pass1", "alias-scan+pass2"]
