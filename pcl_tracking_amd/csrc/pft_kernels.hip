@@ -204,22 +204,32 @@ __global__ void k_pose_to_matrix(const pft_particle* __restrict__ p, uint32_t n,
 // takes particles round-robin (3x4 matrix wave-uniform); transformed points are never stored.
 // Output: per-workgroup partials {min xyz, max xyz}.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_aabb(const float4* __restrict__ ref, uint32_t M,
-                                               const float* __restrict__ mats, uint32_t n_particles,
-                                               float* __restrict__ part, uint32_t lds_points,
-                                               const uint32_t* __restrict__ dyn_n) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (dyn_n) n_particles = *dyn_n;  // KLD variant: particle_num_ lives on the device
-  __shared__ float s_red[6][16];
-  float4* lref = reinterpret_cast<float4*>(smem);
+// (v_min3_f32 / v_max3_f32 by name: fminf / fmaxf carry IEEE quieting that costs a canonicalising v_max per accumulator and
+// iteration, and two points then share one instruction per bound; NaN operands are ignored, as getMinMax3D's compares do)
+__device__ __forceinline__ float amin3(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float amax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// IN_LDS: the reference cloud fits the workgroup's LDS (typed pointer: ds_read_b128, not flat loads); otherwise it is read
+// from global memory / L2
+template <bool IN_LDS>
+__device__ __forceinline__ void aabb_body(const float4* __restrict__ ref, const float4* lref, uint32_t M,
+                                          const float* __restrict__ mats, uint32_t n_particles, float* __restrict__ part,
+                                          float (*s_red)[16]) {
   const int lane = lane_id(), w = wave_id(), nw = blockDim.x >> 6;
   const uint32_t gw = blockIdx.x * nw + w, tw = gridDim.x * nw;
-  const bool in_lds = M <= lds_points;
-  if (in_lds) {
-    for (uint32_t j = threadIdx.x; j < M; j += blockDim.x) lref[j] = ref[j];
+  if (IN_LDS) {
+    float4* wl = const_cast<float4*>(lref);
+    for (uint32_t j = threadIdx.x; j < M; j += blockDim.x) wl[j] = ref[j];
     __syncthreads();
   }
-  const float4* src = in_lds ? lref : ref;
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   for (uint32_t pi = gw; pi < n_particles; pi += tw) {
     float T[12];
@@ -227,21 +237,30 @@ __global__ __launch_bounds__(1024) void k_aabb(const float4* __restrict__ ref, u
     // x' = ((T0 x + T1 y) + T2 z) + T3: the translation is added once per particle, after the reduction -- float
     // addition of a constant is monotone, so min / max over the points of fl(s + T3) equal fl(min / max s + T3) exactly
     float pmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, pmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-#pragma unroll 4
-    for (uint32_t j = lane; j < M; j += WAVE) {
-      float4 r = src[j];
-      const float x = T[0] * r.x + T[1] * r.y + T[2] * r.z;
-      const float y = T[4] * r.x + T[5] * r.y + T[6] * r.z;
-      const float z = T[8] * r.x + T[9] * r.y + T[10] * r.z;
-      pmn[0] = fminf(pmn[0], x); pmx[0] = fmaxf(pmx[0], x);
-      pmn[1] = fminf(pmn[1], y); pmx[1] = fmaxf(pmx[1], y);
-      pmn[2] = fminf(pmn[2], z); pmx[2] = fmaxf(pmx[2], z);
+    uint32_t j = lane;
+    for (; j + WAVE < M; j += 2 * WAVE) {  // two points per step: one three-operand min and max per axis
+      const float4 r = IN_LDS ? lref[j] : ref[j], q = IN_LDS ? lref[j + WAVE] : ref[j + WAVE];
+      const float x0 = T[0] * r.x + T[1] * r.y + T[2] * r.z, x1 = T[0] * q.x + T[1] * q.y + T[2] * q.z;
+      const float y0 = T[4] * r.x + T[5] * r.y + T[6] * r.z, y1 = T[4] * q.x + T[5] * q.y + T[6] * q.z;
+      const float z0 = T[8] * r.x + T[9] * r.y + T[10] * r.z, z1 = T[8] * q.x + T[9] * q.y + T[10] * q.z;
+      pmn[0] = amin3(pmn[0], x0, x1); pmx[0] = amax3(pmx[0], x0, x1);
+      pmn[1] = amin3(pmn[1], y0, y1); pmx[1] = amax3(pmx[1], y0, y1);
+      pmn[2] = amin3(pmn[2], z0, z1); pmx[2] = amax3(pmx[2], z0, z1);
+    }
+    if (j < M) {
+      const float4 r = IN_LDS ? lref[j] : ref[j];
+      const float x0 = T[0] * r.x + T[1] * r.y + T[2] * r.z, y0 = T[4] * r.x + T[5] * r.y + T[6] * r.z,
+                  z0 = T[8] * r.x + T[9] * r.y + T[10] * r.z;
+      pmn[0] = amin3(pmn[0], x0, x0); pmx[0] = amax3(pmx[0], x0, x0);
+      pmn[1] = amin3(pmn[1], y0, y0); pmx[1] = amax3(pmx[1], y0, y0);
+      pmn[2] = amin3(pmn[2], z0, z0); pmx[2] = amax3(pmx[2], z0, z0);
     }
     if (lane < M) {  // (lanes without a point keep their neutral values)
 #pragma unroll
       for (int k = 0; k < 3; k++) {
-        mn[k] = fminf(mn[k], pmn[k] + T[4 * k + 3]);
-        mx[k] = fmaxf(mx[k], pmx[k] + T[4 * k + 3]);
+        const float lo = pmn[k] + T[4 * k + 3], hi = pmx[k] + T[4 * k + 3];
+        mn[k] = amin3(mn[k], lo, lo);
+        mx[k] = amax3(mx[k], hi, hi);
       }
     }
   }
@@ -267,6 +286,19 @@ __global__ __launch_bounds__(1024) void k_aabb(const float4* __restrict__ ref, u
       }
     }
   }
+}
+
+__global__ __launch_bounds__(1024) void k_aabb(const float4* __restrict__ ref, uint32_t M,
+                                               const float* __restrict__ mats, uint32_t n_particles,
+                                               float* __restrict__ part, uint32_t lds_points,
+                                               const uint32_t* __restrict__ dyn_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float s_red[6][16];  // (one static block for both bodies: the dynamic request leaves 512 B for it)
+  if (dyn_n) n_particles = *dyn_n;  // KLD variant: particle_num_ lives on the device
+  if (M <= lds_points)
+    aabb_body<true>(ref, reinterpret_cast<const float4*>(smem), M, mats, n_particles, part, s_red);
+  else
+    aabb_body<false>(ref, nullptr, M, mats, n_particles, part, s_red);
 }
 
 // partials -> b6 = {-xmin,-ymin,-zmin,xmax,ymax,zmax}: one max-reduction (also across ranks) gives the
