@@ -107,6 +107,12 @@ struct pft_tracker {
   uint32_t resample_epoch = 0;
   float trans[16];
 
+  // frame graph (PFT_GRAPH=1, own stream only): the launches of a steady-state frame are captured and replayed as one
+  // hipGraph; the instantiated graph is updated in place while the launch sequence keeps its shape
+  bool use_graph = false;
+  hipGraphExec_t graph_exec = nullptr;
+  uint32_t graph_frames = 0, graph_rebuilds = 0;
+
   // profiling
   bool prof = false;
   std::vector<EvPair> ev[PFT_K_COUNT];
@@ -446,6 +452,10 @@ extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
     t->own_stream = true;
   }
   for (int i = 0; i < 16; i++) t->trans[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+  {
+    const char* ge = getenv("PFT_GRAPH");
+    t->use_graph = ge && ge[0] == '1' && t->own_stream;
+  }
 
   PftParams& p = t->prm;
   memset(&p, 0, sizeof(p));
@@ -538,6 +548,7 @@ extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
 extern "C" void pft_destroy(pft_tracker* t) {
   if (!t) return;
   if (t->stream) hipStreamSynchronize(t->stream);
+  if (t->graph_exec) hipGraphExecDestroy(t->graph_exec);
   for (int k = 0; k < PFT_K_COUNT; k++)
     for (auto& p : t->ev[k]) {
       hipEventDestroy(p.a);
@@ -802,6 +813,12 @@ extern "C" int pft_compute(pft_tracker* t) {
     return PFT_ERR_STATE;
   }
   if (!t->initialized) stage_init_particles(t);
+  // Steady-state frames as ONE graph launch (opt-in): every launch below is recorded instead of issued, and the recorded
+  // graph updates the instantiated one in place (kernel arguments such as the epochs and the particle-buffer parity
+  // change from frame to frame, the node sequence only when the builder choice does: then it is instantiated anew).
+  // The first frames run directly: they set the kernels' one-time attributes, which must not happen during capture.
+  const bool graphed = t->use_graph && t->changed && !t->prof && t->graph_frames++ >= 2u &&
+                       hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
   for (int it = 0; it < t->cfg.iteration_num; it++) {
     if (t->changed) stage_resample(t);
     sync_dev(t);
@@ -816,6 +833,34 @@ extern "C" int pft_compute(pft_tracker* t) {
       pftk_population(t->stream, t->prm, t->dev, t->prm.kld ? t->Pcap : t->prm.P_total, 1, 1, 1, 1);
     }
     t->changed = true;
+  }
+  if (graphed) {
+    hipGraph_t g = nullptr;
+    hipError_t ge = hipStreamEndCapture(t->stream, &g);
+    if (ge == hipSuccess && g) {
+      bool ready = false;
+      if (t->graph_exec) {
+        hipGraphNode_t bad = nullptr;
+        hipGraphExecUpdateResult res;
+        ready = hipGraphExecUpdate(t->graph_exec, g, &bad, &res) == hipSuccess;
+        if (!ready) {
+          (void)hipGetLastError();
+          hipGraphExecDestroy(t->graph_exec);
+          t->graph_exec = nullptr;
+        }
+      }
+      if (!ready) {
+        ge = hipGraphInstantiate(&t->graph_exec, g, nullptr, nullptr, 0);
+        t->graph_rebuilds++;
+        ready = ge == hipSuccess;
+      }
+      if (ready) ge = hipGraphLaunch(t->graph_exec, t->stream);
+      hipGraphDestroy(g);
+    }
+    if (ge != hipSuccess) {
+      t->err = std::string("frame graph: ") + hipGetErrorString(ge);
+      return PFT_ERR_HIP;
+    }
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

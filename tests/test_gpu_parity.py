@@ -320,6 +320,29 @@ def test_compute_moving_sequence(gpu, orc, data):
             assert abs(float(rg[k]) - float(ro[k])) < 1e-4
 
 
+def test_frame_graph_mode_is_bit_identical(gpu, data, monkeypatch):
+    """PFT_GRAPH=1 (opt-in): the launches of a steady-state frame are captured and replayed as one hipGraph, updated in
+    place from frame to frame.  Same kernels, same arguments: the results must not change by a bit.  (Measured on the
+    headline workload it is no faster -- 0.546 against 0.539 ms per frame -- so it is not the default: DESIGN.md 5.)"""
+    def run(graph):
+        if graph:
+            monkeypatch.setenv("PFT_GRAPH", "1")
+        else:
+            monkeypatch.delenv("PFT_GRAPH", raising=False)
+        t = gpu.make_reference_tracker(particle_num=1024, seed=12)
+        t.setReferenceCloud(data["model"])
+        t.setTrans(scene.initial_trans())
+        out = []
+        for f in range(8):  # the first frames run directly, then the graph takes over; the crop size changes on the way
+            t.setInputCloud(data["scene"][:20000 + 4000 * f])
+            t.compute()
+            out.append(t.getResult().tobytes())
+        out.append(t.getParticles().tobytes())
+        return out
+
+    assert run(True) == run(False)
+
+
 def test_error_behaviour(gpu):
     from pcl_tracking_amd._lib import PftError
 
