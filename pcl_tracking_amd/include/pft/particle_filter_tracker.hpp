@@ -285,13 +285,13 @@ class ParticleFilterTracker {
     size_t n = 0;
     pft_get_particles(handle_, nullptr, 0, &n);
     out->points.resize(n);
-    if (n) pft_get_particles(handle_, out->points.data(), n, &n);
+    if (n) check(pft_get_particles(handle_, out->points.data(), n, &n), "getParticles");
     out->width = (uint32_t)n;
     return out;
   }
   double getFitRatio() const {
     double v = 0.0;
-    if (handle_) pft_get_fit_ratio(handle_, &v);
+    if (handle_) check(pft_get_fit_ratio(handle_, &v), "getFitRatio");
     return v;
   }
   int getIterationNum() const { return cfg_.iteration_num; }
