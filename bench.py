@@ -87,7 +87,7 @@ def spawn_ranks_if_needed():
     import torch  # device_count() reads the driver's list and does not initialise the GPU
 
     ndev = torch.cuda.device_count()
-    if ndev < ARGS.gpus:
+    if ndev < ARGS.gpus and not (os.environ.get("PFT_BENCH_SHARE_GPU") == "1" and ndev >= 1):
         sys.stderr.write("bench.py: --gpus %d but %d GPU(s) are visible on this machine: refusing to run fewer ranks "
                          "and report them as %d\n" % (ARGS.gpus, ndev, ARGS.gpus))
         sys.exit(2)
@@ -231,6 +231,11 @@ def main():
             sys.stderr.write("bench: rebuild skipped (%s)\n" % e)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    # PFT_BENCH_SHARE_GPU=1: rehearsal of the N-rank control flow on a one-GPU box -- every rank on cuda:0, collectives
+    # through gloo with host staging (RCCL refuses two ranks on one device).  The numbers of such a run mean nothing.
+    share_gpu = os.environ.get("PFT_BENCH_SHARE_GPU") == "1" and world > 1
+    if share_gpu:
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         raise SystemExit("rank %d: LOCAL_RANK %d but %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
@@ -240,7 +245,10 @@ def main():
     if use_dist:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     P_local = ARGS.particles_per_gpu
     sharded = world > 1 and ARGS.objects == 1  # several objects are replicas (one handle each), never sharded
@@ -325,7 +333,7 @@ def main():
             run_frame(restore)
         sync()
         dt = time.perf_counter() - t0
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else dev)
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
@@ -336,7 +344,7 @@ def main():
     dt_other = timed(not replay)  # the other mode, reported beside the headline
 
     # ranks that actually took part (never a constant: a launch that lost ranks must not report them)
-    took_part = torch.ones(1, dtype=torch.int32, device=dev)
+    took_part = torch.ones(1, dtype=torch.int32, device="cpu" if share_gpu else dev)
     if world > 1:
         dist.all_reduce(took_part)
     n_ranks = int(took_part.item())
@@ -360,12 +368,14 @@ def main():
         lik_ms, lik_n = prof["likelihood"]
     lik_avg_s = lik_ms / max(1, lik_n) * 1e-3
 
+    # mean leaf occupancy of the replayed frame's second likelihood launch (counted on the device, outside the timed
+    # region): the particles after a replayed step are exactly the ones that launch evaluated.  (Every rank replays: a
+    # sharded frame has collectives in it.)
+    if replay:
+        run_frame(True)
+        sync()
     out = None
     if rank == 0:
-        # mean leaf occupancy of the replayed frame's second likelihood launch (counted on the device, outside the
-        # timed region): the particles after a replayed step are exactly the ones that launch evaluated
-        if replay:
-            run_frame(True)
         pcur = trk.getParticles()
         if sharded:
             pcur = pcur[rank * P_local:(rank + 1) * P_local]
@@ -400,7 +410,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not share_gpu else "synthetic -- REHEARSAL: all ranks share one GPU through gloo, the numbers mean nothing",
             "config": {
                 "workload": workload_label(P_local, M, N, ARGS.organized, n_obj, world),
                 "mode": "replayed frame (state checkpointed after the warm-up, restored before every step)" if replay

@@ -180,3 +180,36 @@ def test_sharded_rehearsal_on_one_gpu(tmp_path, orc, world):
         ro = o.get_result()
         for k in KEYS:
             assert abs(float(want[f][k]) - float(ro[k])) < 1e-4
+
+
+@pytest.mark.timeout(900)
+def test_bench_launches_its_ranks_itself(tmp_path):
+    """`python bench.py --gpus N` as the driver invokes it, without a launcher: it must start N ranks itself or fail
+    loudly, never run one rank and call it N.  On this one-GPU box: --gpus 2 is an error exit; with the rehearsal switch
+    (both ranks on cuda:0, gloo) the whole N-rank control flow runs -- self-spawn through torch.distributed.run, sharded
+    frames with their two collectives, the replayed checkpoint, max-over-ranks timing -- and reports the ranks that took
+    part."""
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PFT_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "3", "--warmup", "1"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode == 2 and "refusing" in r.stderr, (r.returncode, r.stderr[-500:])
+    assert "n_gpus" not in r.stdout
+    # a launcher that disagrees with --gpus is an error as well
+    env1 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], capture_output=True, text=True, env=env1, timeout=300)
+    assert r.returncode == 2
+    env["PFT_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "4", "--warmup", "2"], capture_output=True, text=True,
+                       env=env, timeout=800)
+    assert r.returncode == 0, r.stderr[-1500:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["particles_total"] == 16384
+    assert "sharded x2" in d["config"]["parallelism"] and "REHEARSAL" in d["data"]
+    assert d["ms_per_step"] > 0 and d["cropped_points"] > 1000

@@ -35,6 +35,7 @@ for i in range(frames):
         if free0 is None and i > 0:
             free0 = free
         ok = all(np.isfinite(float(r[c])) and np.isfinite(float(rk[c])) for c in ("x", "y", "z", "roll", "pitch", "yaw"))
+        ok = ok and (t.debugHostStat()[2:] == 0).all() and (k.debugHostStat()[2:] == 0).all()  # no device-side failure, ever
         print("frame %6d  %.1f s  free %.1f MiB  pose x=%.4f z=%.4f  kld particles %d  finite=%s" % (
             i, time.time() - t0, free / 2**20, float(r["x"]), float(r["z"]), len(k.getParticles()), ok), flush=True)
         assert ok
