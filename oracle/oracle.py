@@ -78,6 +78,8 @@ def lib():
     L.orc_normalize_weights.argtypes = [vp, sz, f64, P(f64)]
     L.orc_gen_alias_table.argtypes = [vp, sz, vp, vp]
     L.orc_weighted_mean.argtypes = [vp, sz, vp]
+    L.orc_normalize_weights_tree.argtypes = [vp, sz, f64, P(f64)]
+    L.orc_weighted_mean_tree.argtypes = [vp, sz, vp]
     L.orc_philox4x32.argtypes = [vp, vp, vp]
     L.orc_u53.argtypes = [u32, u32]
     L.orc_u53.restype = f64
@@ -232,6 +234,14 @@ def normalize_weights(w, alpha=15.0):
     return w, fr.value
 
 
+def normalize_weights_tree(w, alpha=15.0):
+    """normalizeWeight with the weight sum taken as the adjacent-pair tree (sum mode 1)"""
+    w = np.array(w, np.float32, copy=True)
+    fr = C.c_double()
+    lib().orc_normalize_weights_tree(_ptr(w), len(w), alpha, C.byref(fr))
+    return w, fr.value
+
+
 def gen_alias_table(w):
     w = np.ascontiguousarray(w, np.float32)
     a = np.zeros(len(w), np.int32)
@@ -244,6 +254,14 @@ def weighted_mean(p):
     p = np.ascontiguousarray(p, PARTICLE_DTYPE)
     out = np.zeros(1, PARTICLE_DTYPE)
     lib().orc_weighted_mean(_ptr(p), len(p), _ptr(out))
+    return out[0]
+
+
+def weighted_mean_tree(p):
+    """update() with the six weighted-pose sums taken as adjacent-pair trees in double (sum mode 1)"""
+    p = np.ascontiguousarray(p, PARTICLE_DTYPE)
+    out = np.zeros(1, PARTICLE_DTYPE)
+    lib().orc_weighted_mean_tree(_ptr(p), len(p), _ptr(out))
     return out[0]
 
 

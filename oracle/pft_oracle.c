@@ -510,7 +510,7 @@ static size_t pow2_at_least(size_t n) {
   return m;
 }
 
-static void normalize_weights_tree(float* w, size_t n, double alpha, double* fit_ratio) {
+void orc_normalize_weights_tree(float* w, size_t n, double alpha, double* fit_ratio) {
   double w_min = DBL_MAX, w_max = -DBL_MAX;
   for (size_t i = 0; i < n; i++) {
     double weight = w[i];
@@ -535,7 +535,7 @@ static void normalize_weights_tree(float* w, size_t n, double alpha, double* fit
   }
 }
 
-static void weighted_mean_tree(const orc_particle_t* p, size_t n, orc_particle_t* rep) {
+void orc_weighted_mean_tree(const orc_particle_t* p, size_t n, orc_particle_t* rep) {
   orc_particle_t r;
   memset(&r, 0, sizeof(r));
   r.w = 1.0f;
@@ -1043,7 +1043,7 @@ static void tracker_weight(orc_tracker_t* t) {
   t->changed = 1;
   double t0 = omp_get_wtime();
   if (t->sum_mode == 1)
-    normalize_weights_tree(w, P, t->cfg.alpha, &t->fit_ratio);
+    orc_normalize_weights_tree(w, P, t->cfg.alpha, &t->fit_ratio);
   else
     orc_normalize_weights(w, P, t->cfg.alpha, &t->fit_ratio);
   for (size_t i = 0; i < P; i++) t->particles[i].weight = w[i];
@@ -1076,7 +1076,7 @@ static void tracker_update(orc_tracker_t* t) {
   double t0 = omp_get_wtime();
   orc_particle_t orig = t->rep, r;
   if (t->sum_mode == 1)
-    weighted_mean_tree(t->particles, t->P, &r);
+    orc_weighted_mean_tree(t->particles, t->P, &r);
   else
     orc_weighted_mean(t->particles, t->P, &r);
   t->rep = r;

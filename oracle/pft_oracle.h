@@ -142,6 +142,10 @@ void orc_tracker_set_trig_mode(orc_tracker_t* t, int mode);
 /* tests only: 0 (default) = PCL's sequential weight sum (double) and weighted mean (float); 1 = the order the product
  * specifies for its parallel reductions: adjacent-pair tree over the index range padded to a power of two, in double */
 void orc_tracker_set_sum_mode(orc_tracker_t* t, int mode);
+/* the two stages of sum mode 1 on explicit arrays (same exp / division as orc_normalize_weights and the same products as
+ * orc_weighted_mean; only the order of the additions differs: adjacent-pair tree in double) */
+void orc_normalize_weights_tree(float* w, size_t n, double alpha, double* fit_ratio);
+void orc_weighted_mean_tree(const orc_particle_t* p, size_t n, orc_particle_t* rep);
 /* tests of the particle-sharded host logic: crop with this box (the reduction over all ranks) instead of
  * the box of the given particles; bbox_only stops eval_weights after calcBoundingBox */
 void orc_tracker_set_bbox_override(orc_tracker_t* t, const double* bbox6);

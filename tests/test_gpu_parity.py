@@ -284,6 +284,29 @@ def test_weighted_mean(gpu, orc, data):
         assert got["weight"] == want["weight"]
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 159, 400, 500, 1000, 4097, 8192, 16385, 40000, 65536, 300000])
+def test_population_sums_follow_the_specified_tree(gpu, orc, n):
+    """The weight sum and the weighted mean are ADJACENT-PAIR TREES in double over the index range padded to a power of
+    two (pft_population.hip): whatever the number of workgroups and particles per thread the launcher picks for n, the
+    results equal the oracle's restatement of that order bit for bit -- and PCL's sequential order to
+    the tolerances of test_normalize / test_weighted_mean above."""
+    g = gpu.make_reference_tracker(particle_num=64)
+    rng = np.random.default_rng(n)
+    p = particles_around(scene.model_gt_pose(), n, n + 1)
+    w = rng.random(n).astype(np.float32)
+    p["weight"] = w / w.sum()
+    got, want = g.debugWeightedMean(p), orc.weighted_mean_tree(p)
+    assert got.tobytes() == want.tobytes(), (got, want)
+    raw = (-rng.random(n) * 80 - 900).astype(np.float32)
+    raw[rng.random(n) < 0.05] = 0.0
+    gw, gf = g.debugNormalize(raw)
+    ow, of = orc.normalize_weights_tree(raw)
+    assert gf == of
+    # exp() in double on both sides (ocml / glibc): the cast to float agrees except in rare last-bit cases
+    d = ulp_diff(gw, ow)
+    assert d.max() <= 1 and (d == 0).mean() > 0.999, (int(d.max()), float((d == 0).mean()))
+
+
 # ---- A12: the whole tracker -------------------------------------------------------------------------------
 @pytest.mark.parametrize("P", [400, 8192])
 def test_compute_tracks_like_oracle(gpu, orc, data, P):

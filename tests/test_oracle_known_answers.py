@@ -358,3 +358,41 @@ def test_kld_resample_stops_at_the_bound(orc):
     # bins are truncations toward zero of value / 0.1f
     v = np.stack([p[c] for c in ("x", "y", "z", "roll", "pitch", "yaw")], 1)
     np.testing.assert_array_equal(bins, (v / np.float32(0.1)).astype(np.int32))
+
+
+# ---- the oracle's test-only summation order (sum mode 1): the tree the product specifies for its reductions ----
+def test_tree_order_weighted_mean_known_answer(orc):
+    """Adjacent-pair tree in double over the index range padded to a power of two: ((x0 + x1) + (x2 + x3)) + ...  With
+    x = {2^60, 1, -2^60, 1} (weights 1) PCL's sequential float sum gives 1 (the first 1 is absorbed, the second
+    survives), the tree gives 0 (both are absorbed inside their pairs): the two orders are told apart."""
+    import numpy as np
+
+    p = np.zeros(4, orc.PARTICLE_DTYPE)
+    p["x"] = [2.0 ** 60, 1.0, -(2.0 ** 60), 1.0]
+    p["y"] = [1.0, 2.0, 3.0, 4.0]
+    p["weight"] = 1.0
+    seq, tree = orc.weighted_mean(p), orc.weighted_mean_tree(p)
+    assert float(seq["x"]) == 1.0 and float(tree["x"]) == 0.0
+    assert float(seq["y"]) == 10.0 and float(tree["y"]) == 10.0
+    assert float(tree["weight"]) == 0.25 and float(tree["w"]) == 1.0
+    # five elements: padded to eight with +0.0; ((a+b)+(c+d)) + ((e+0)+(0+0))
+    q = np.zeros(5, orc.PARTICLE_DTYPE)
+    q["z"] = [1.0, 2.0 ** -30, 2.0 ** -30, 1.0, 2.0 ** -60]
+    q["weight"] = 1.0
+    want = ((1.0 + 2.0 ** -30) + (2.0 ** -30 + 1.0)) + ((2.0 ** -60 + 0.0) + 0.0)
+    assert float(orc.weighted_mean_tree(q)["z"]) == np.float32(want)
+
+
+def test_tree_order_normalize_matches_the_sequential_one_up_to_the_sum(orc):
+    import numpy as np
+
+    rng = np.random.default_rng(3)
+    raw = -rng.random(1000).astype(np.float32) * 50 - 1000
+    raw[::17] = 0.0  # particles without a correspondence keep weight zero
+    a, fa = orc.normalize_weights(raw)
+    b, fb = orc.normalize_weights_tree(raw)
+    assert fa == fb == float(raw.min())
+    assert (a[::17] == 0).all() and (b[::17] == 0).all()
+    d = np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+    assert d.max() <= 1  # only (float) sum can differ, by one ulp at most
+    assert abs(float(b.astype(np.float64).sum()) - 1.0) < 1e-5
