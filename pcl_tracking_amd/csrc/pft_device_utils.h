@@ -20,6 +20,27 @@ __device__ __forceinline__ T wave_sum(T v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// Sum of a double over the 64 lanes with DPP moves instead of ds_bpermute shuffles: 6 steps of two v_mov_dpp and one
+// v_add_f64 (the shuffle form is 7 instructions per step).  Fixed order: inside the quads, inside the rows of 16, then
+// row 0 into row 1 / row 2 into row 3 (row_bcast15), then rows 0+1 into rows 2, 3 (row_bcast31).  The total is valid in
+// lane 63 ONLY (returned there; other lanes hold partial sums).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_f64(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (unsigned long long)(uint32_t)lo));
+}
+__device__ __forceinline__ double wave_sum_lane63(double v) {
+  v += dpp_move_f64<0xb1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dpp_move_f64<0x4e, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += dpp_move_f64<0x124, 0xf>(v);  // row_ror 4
+  v += dpp_move_f64<0x128, 0xf>(v);  // row_ror 8: every lane of a row now holds the row's sum
+  v += dpp_move_f64<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3 (lanes of rows 0, 2 add the old value 0)
+  v += dpp_move_f64<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3
+  return v;
+}
+
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));

@@ -379,8 +379,8 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         val += rcp_nr(A * Bq);
       }
     }
-    val = wave_sum(val);
-    if (lane == 0) d.partial[(size_t)pi * nchunk + ch] = val;
+    val = wave_sum_lane63(val);  // (DPP: 18 instructions against 42 for the shuffle butterfly; the total lands in lane 63)
+    if (lane == 63) d.partial[(size_t)pi * nchunk + ch] = val;
     {
       uint32_t nx = 0;
       if (lane == 0) nx = it_begin + waves_in_grp + atomicAdd(ctr, 1u);
