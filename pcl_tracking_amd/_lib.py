@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "libpft_hip.so")
+# PFT_LIB_PATH: another build of the same HIP library (A/B timing of compile-time variants, tools/build_variant.py)
+LIB_PATH = os.environ.get("PFT_LIB_PATH") or os.path.join(_HERE, "_build", "libpft_hip.so")
 
 PFT_ABI_VERSION = 4
 K_RESAMPLE, K_AABB, K_CROP, K_OCTREE, K_LIKELIHOOD, K_POPULATION, K_PACK, K_COUNT = range(8)
