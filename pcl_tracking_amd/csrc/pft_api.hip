@@ -73,6 +73,12 @@ struct pft_tracker {
   uint32_t *d_eg_start = nullptr, *d_eg_cnt = nullptr, *d_eg_tile = nullptr;
   uint32_t *d_ec_slot = nullptr, *d_ec_cells = nullptr, *d_ec_count = nullptr, *d_ec_base = nullptr;
   float4* d_ec_list = nullptr;
+  // exact-NN mode, cell-sorted queries (sized by the largest particle count x reference size evaluated so far)
+  uint32_t *d_eq_cellq = nullptr, *d_eq_nq = nullptr, *d_eq_qbase = nullptr, *d_eq_bbase = nullptr, *d_eq_fill = nullptr,
+           *d_eq_blk = nullptr;
+  float4* d_eq_sorted = nullptr;
+  double* d_eq_out = nullptr;
+  uint32_t eq_cap = 0, eq_blk_cap = 0;
   uint32_t* d_kld_table = nullptr;
   int32_t* d_kld_bins = nullptr;
   uint32_t dbg_builds = 0;
@@ -347,6 +353,16 @@ static void sync_dev(pft_tracker* t) {
   d.ec_count = t->d_ec_count;
   d.ec_base = t->d_ec_base;
   d.ec_list = t->d_ec_list;
+  d.eq_cellq = t->d_eq_cellq;
+  d.eq_nq = t->d_eq_nq;
+  d.eq_qbase = t->d_eq_qbase;
+  d.eq_bbase = t->d_eq_bbase;
+  d.eq_fill = t->d_eq_fill;
+  d.eq_blk = t->d_eq_blk;
+  d.eq_sorted = t->d_eq_sorted;
+  d.eq_out = t->d_eq_out;
+  d.eq_cap = t->eq_cap;
+  d.eq_blk_cap = t->eq_blk_cap;
   d.kld_table = t->d_kld_table;
   d.kld_bins = t->d_kld_bins;
   d.alias_pos = t->d_alias_pos;
@@ -514,6 +530,11 @@ extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
     A(dalloc(&t->d_ec_count, (size_t)PFT_EC_SLOTS));
     A(dalloc(&t->d_ec_base, (size_t)PFT_EC_SLOTS));
     A(dalloc(&t->d_ec_list, (size_t)PFT_EC_POOL));
+    A(dalloc(&t->d_eq_cellq, (size_t)PFT_EG_CAP));
+    A(dalloc(&t->d_eq_nq, (size_t)PFT_EC_SLOTS));
+    A(dalloc(&t->d_eq_qbase, (size_t)PFT_EC_SLOTS));
+    A(dalloc(&t->d_eq_bbase, (size_t)PFT_EC_SLOTS));
+    A(dalloc(&t->d_eq_fill, (size_t)PFT_EC_SLOTS));
   }
   if (p.kld) {
     A(dalloc(&t->d_kld_table, (size_t)6 * p.kld_max + 128));
@@ -566,7 +587,7 @@ extern "C" void pft_destroy(pft_tracker* t) {
   dfree(t->d_pt_key64); dfree(t->sort.keys[0]); dfree(t->sort.keys[1]); dfree(t->sort.vals[0]); dfree(t->sort.vals[1]);
   dfree(t->sort.hist); dfree(t->sort.tile_cnt); dfree(t->sort.tile_box); if (t->h_stat) hipHostFree(t->h_stat);
   dfree(t->d_partial); dfree(t->d_alias_list); dfree(t->d_alias_pos); dfree(t->d_raw_w);
-  dfree(t->d_alias_pref); dfree(t->d_pop_part); dfree(t->d_kld_table); dfree(t->d_kld_bins); dfree(t->d_eg_start); dfree(t->d_eg_cnt); dfree(t->d_eg_tile); dfree(t->d_ec_slot); dfree(t->d_ec_cells); dfree(t->d_ec_count); dfree(t->d_ec_base); dfree(t->d_ec_list); dfree(t->d_hdr); dfree(t->d_nn_idx); dfree(t->d_nn_d2); dfree(t->d_dbg_part);
+  dfree(t->d_alias_pref); dfree(t->d_pop_part); dfree(t->d_kld_table); dfree(t->d_kld_bins); dfree(t->d_eg_start); dfree(t->d_eg_cnt); dfree(t->d_eg_tile); dfree(t->d_ec_slot); dfree(t->d_ec_cells); dfree(t->d_ec_count); dfree(t->d_ec_base); dfree(t->d_ec_list); dfree(t->d_eq_cellq); dfree(t->d_eq_nq); dfree(t->d_eq_qbase); dfree(t->d_eq_bbase); dfree(t->d_eq_fill); dfree(t->d_eq_blk); dfree(t->d_eq_sorted); dfree(t->d_eq_out); dfree(t->d_hdr); dfree(t->d_nn_idx); dfree(t->d_nn_d2); dfree(t->d_dbg_part);
   dfree(t->d_dbg_hdr); dfree(t->d_dbg_f);
   dfree(t->sv_part); dfree(t->sv_alias_list); dfree(t->sv_alias_pref); dfree(t->sv_alias_pos); dfree(t->sv_hdr);
   if (t->own_stream && t->stream) hipStreamDestroy(t->stream);
@@ -754,12 +775,38 @@ static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32
     }
   }
   if (t->cfg.exact_nearest) {  // NearestPairPointCloudCoherence: uniform grid + true nearest neighbour, no octree
+    PftDev dq = d;
+    {
+      // the cell-sorted query arrays grow to the largest evaluation seen (16 + 8 bytes per query, up to 2^30 queries;
+      // beyond that, or if the allocation fails, the per-query kernel serves)
+      const unsigned long long nq = (unsigned long long)np * t->prm.M;
+      if (nq > t->eq_cap && nq <= (1ull << 30)) {
+        dfree(t->d_eq_sorted); dfree(t->d_eq_out); dfree(t->d_eq_blk);
+        t->d_eq_sorted = nullptr; t->d_eq_out = nullptr; t->d_eq_blk = nullptr;
+        t->eq_cap = t->eq_blk_cap = 0;
+        const size_t nblk = (size_t)(nq / 64u) + PFT_EC_SLOTS + 64u;
+        if (dalloc(&t->d_eq_sorted, (size_t)nq) == hipSuccess && dalloc(&t->d_eq_out, (size_t)nq) == hipSuccess &&
+            dalloc(&t->d_eq_blk, nblk) == hipSuccess) {
+          t->eq_cap = (uint32_t)nq;
+          t->eq_blk_cap = (uint32_t)nblk;
+        } else {
+          (void)hipGetLastError();
+          dfree(t->d_eq_sorted); dfree(t->d_eq_out); dfree(t->d_eq_blk);
+          t->d_eq_sorted = nullptr; t->d_eq_out = nullptr; t->d_eq_blk = nullptr;
+        }
+      }
+      dq.eq_sorted = t->d_eq_sorted;
+      dq.eq_out = t->d_eq_out;
+      dq.eq_blk = t->d_eq_blk;
+      dq.eq_cap = t->eq_cap;
+      dq.eq_blk_cap = t->eq_blk_cap;
+    }
     {
       ProfScope ps(t, PFT_K_OCTREE);
       pftk_exact_grid(t->stream, t->prm, d);
     }
     ProfScope ps(t, PFT_K_LIKELIHOOD);
-    pftk_likelihood_exact(t->stream, t->prm, d, np, debug_nn, t->num_cus);
+    pftk_likelihood_exact(t->stream, t->prm, dq, np, debug_nn, t->num_cus);
     return;
   }
   {
@@ -1208,6 +1255,14 @@ extern "C" int pft_debug_get_descent_stats(pft_tracker* t, uint64_t* dbg32) {
   int r = read_hdr(t, &h);
   if (r != PFT_OK) return r;
   for (int i = 0; i < 32; i++) dbg32[i] = h.dbg[i];
+  if (t->cfg.exact_nearest) {  // the exact-NN mode's bookkeeping of the last iteration (tools/exact_nn_bench.py)
+    dbg32[8] = h.ec_nslots;
+    dbg32[9] = h.ec_pool_used;
+    dbg32[10] = h.eq_totals & 0xffffffffull;
+    dbg32[11] = h.eq_totals >> 32;
+    dbg32[12] = h.eg_ncells;
+    dbg32[13] = h.n_crop;
+  }
   return PFT_OK;
 }
 

@@ -53,6 +53,7 @@ __global__ void k_eg_setup(PftParams prm, PftDev d) {
   h->eg_ncells = n > 0 ? (uint32_t)(dim[0] * dim[1] * dim[2]) : 0u;
   h->ec_nslots = 0u;
   h->ec_pool_used = 0u;
+  h->eq_totals = 0ull;
 }
 
 __global__ __launch_bounds__(256) void k_eg_zero(PftDev d) {
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(256) void k_eg_zero(PftDev d) {
   for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < min(nc, (blockIdx.x + 1u) * 1024u); i += 256u) {
     d.eg_cnt[i] = 0u;
     d.ec_slot[i] = 0u;
+    d.eq_cellq[i] = 0u;
   }
 }
 
@@ -170,18 +172,49 @@ __device__ __forceinline__ bool eg_query_cell(const PftHeader* h, float qx, floa
   return cx >= 0 && cx < h->eg_dim[0] && cy >= 0 && cy < h->eg_dim[1] && cz >= 0 && cz < h->eg_dim[2];
 }
 
-// every query flags its cell
-__global__ __launch_bounds__(256) void k_ec_mark(PftParams prm, PftDev d, uint32_t n_particles) {
-  PftHeader* h = d.hdr;
-  if (h->n_crop == 0) return;
-  if (d.p_active) n_particles = *d.p_active;
+// ---- the queries of a workgroup's tile of particles, aggregated by cell in LDS ----
+// Sixteen million global atomics (one per query) take 1.5 ms; the queries of neighbouring particles fall into the same
+// few thousand cells, so a workgroup first counts its tile in an LDS hash table (cell -> count) and then issues one
+// global atomic per cell it has seen.  A cell that finds its probe window full is counted with global atomics directly
+// (wide particle clouds); the window is a function of the table's final state only, so every query of a cell takes
+// the same route in every pass.
+#define EQ_TAB 8192u  // entries; 64 KiB with the values
+#define EQ_EMPTY 0xffffffffu
+#define EQ_PROBES 48
+
+__device__ __forceinline__ uint32_t eq_hash(uint32_t c) { return (c * 2654435761u) >> 19; }  // 13 bits
+
+__device__ __forceinline__ uint32_t eq_insert(uint32_t* key, uint32_t c) {
+  uint32_t hh = eq_hash(c);
+  for (int probe = 0; probe < EQ_PROBES; probe++) {
+    uint32_t k = key[hh];
+    if (k == EQ_EMPTY) k = atomicCAS(&key[hh], EQ_EMPTY, c);
+    if (k == c || k == EQ_EMPTY) return hh;
+    hh = (hh + 1u) & (EQ_TAB - 1u);
+  }
+  return EQ_TAB;
+}
+
+__device__ __forceinline__ uint32_t eq_find(const uint32_t* key, uint32_t c) {
+  uint32_t hh = eq_hash(c);
+  for (int probe = 0; probe < EQ_PROBES; probe++) {
+    const uint32_t k = key[hh];
+    if (k == c) return hh;
+    if (k == EQ_EMPTY) return EQ_TAB;
+    hh = (hh + 1u) & (EQ_TAB - 1u);
+  }
+  return EQ_TAB;
+}
+
+// one pass of a workgroup over the queries of its particles [p0, p1): f(particle, reference position, qx, qy, qz)
+template <class F>
+__device__ __forceinline__ void eq_tile_queries(const PftParams& prm, const PftDev& d, uint32_t p0, uint32_t p1, F&& f) {
   const uint32_t M = prm.M, nblk = (M + 511u) / 512u;
-  const int lane = lane_id(), nw = blockDim.x >> 6;
-  const uint32_t gw = blockIdx.x * nw + wave_id(), tw = gridDim.x * nw;
-  const uint32_t n_items = n_particles * nblk;
-  for (uint32_t item_v = gw; item_v < n_items; item_v += tw) {
+  const uint32_t lane = (uint32_t)lane_id(), nw = blockDim.x >> 6;
+  const uint32_t n_items = (p1 - p0) * nblk;
+  for (uint32_t item_v = wave_id(); item_v < n_items; item_v += nw) {
     const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item_v);
-    const uint32_t pi = item / nblk, ch = item % nblk;
+    const uint32_t pi = p0 + item / nblk, ch = item % nblk;
     float T[12];
     load_matrix(d.mats, pi, T);
     const uint32_t jend = min(M, (ch + 1u) * 512u);
@@ -189,31 +222,76 @@ __global__ __launch_bounds__(256) void k_ec_mark(PftParams prm, PftDev d, uint32
       const float4 r = d.ref_xyz[j];
       float qx, qy, qz;
       xform(T, r.x, r.y, r.z, qx, qy, qz);
-      int cx, cy, cz;
-      if (!eg_query_cell(h, qx, qy, qz, cx, cy, cz)) continue;
-      const uint32_t c = (uint32_t)((cz * h->eg_dim[1] + cy) * h->eg_dim[0] + cx);
-      if (d.ec_slot[c] == 0u) d.ec_slot[c] = 1u;  // idempotent: no atomic needed
+      f(pi, j, qx, qy, qz);
     }
   }
 }
 
-// the flagged cells get list slots (order irrelevant)
+// every query counts itself in its cell
+__global__ __launch_bounds__(1024) void k_ec_mark(PftParams prm, PftDev d, uint32_t n_particles, uint32_t ppw) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t eq_lds[];
+  uint32_t* key = eq_lds;
+  uint32_t* val = eq_lds + EQ_TAB;
+  const PftHeader* h = d.hdr;
+  if (h->n_crop == 0) return;
+  if (d.p_active) n_particles = *d.p_active;
+  const uint32_t p0 = min(n_particles, blockIdx.x * ppw), p1 = min(n_particles, p0 + ppw);
+  if (p0 >= p1) return;
+  for (uint32_t e = threadIdx.x; e < EQ_TAB; e += blockDim.x) {
+    key[e] = EQ_EMPTY;
+    val[e] = 0u;
+  }
+  __syncthreads();
+  const int dx_ = h->eg_dim[0], dy_ = h->eg_dim[1];
+  eq_tile_queries(prm, d, p0, p1, [&](uint32_t, uint32_t, float qx, float qy, float qz) {
+    int cx, cy, cz;
+    if (!eg_query_cell(h, qx, qy, qz, cx, cy, cz)) return;
+    const uint32_t c = (uint32_t)((cz * dy_ + cy) * dx_ + cx);
+    const uint32_t e = eq_insert(key, c);
+    if (e < EQ_TAB)
+      atomicAdd(&val[e], 1u);
+    else
+      atomicAdd(&d.eq_cellq[c], 1u);
+  });
+  __syncthreads();
+  for (uint32_t e = threadIdx.x; e < EQ_TAB; e += blockDim.x)
+    if (key[e] != EQ_EMPTY && val[e]) atomicAdd(&d.eq_cellq[key[e]], val[e]);
+}
+
+// the cells with queries get list slots (order irrelevant) -- and, for the cell-sorted search, their segment of the
+// sorted query array and their 64-query blocks: three running totals, one 64-bit and one 32-bit atomic per wave
 __global__ __launch_bounds__(256) void k_ec_slots(PftDev d) {
   PftHeader* h = d.hdr;
   const uint32_t nc = h->n_crop ? h->eg_ncells : 0u;
+  const int lane = lane_id();
   for (uint32_t c0 = blockIdx.x * 256u; c0 < nc; c0 += gridDim.x * 256u) {
     const uint32_t c = c0 + threadIdx.x;
-    const bool hit = c < nc && d.ec_slot[c] == 1u;
+    const uint32_t nq = c < nc ? d.eq_cellq[c] : 0u;
+    const bool hit = nq != 0u;
     const unsigned long long m = __ballot(hit);
     if (!m) continue;
+    const uint32_t nb = (nq + 63u) >> 6;
+    const unsigned long long mine = ((unsigned long long)nb << 32) | nq;  // (blocks << 32) | queries
+    const unsigned long long incl = wave_incl_scan(mine);
+    const int first = __ffsll((long long)m) - 1;
     uint32_t base = 0;
-    if (lane_id() == __ffsll((long long)m) - 1) base = atomicAdd(&h->ec_nslots, (uint32_t)__popcll(m));
-    base = (uint32_t)__shfl((int)base, __ffsll((long long)m) - 1);
+    unsigned long long qb = 0;
+    if (lane == first) base = atomicAdd(&h->ec_nslots, (uint32_t)__popcll(m));
+    if (lane == WAVE - 1) qb = atomicAdd(&h->eq_totals, incl);
+    base = (uint32_t)__shfl((int)base, first);
+    qb = __shfl(qb, WAVE - 1) + incl - mine;
     if (hit) {
-      const uint32_t sl = base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+      const uint32_t sl = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
       if (sl < PFT_EC_SLOTS) {
         d.ec_cells[sl] = c;
+        d.eq_nq[sl] = nq;
+        d.eq_qbase[sl] = (uint32_t)qb;
+        d.eq_bbase[sl] = (uint32_t)(qb >> 32);
+        d.eq_fill[sl] = 0u;
         d.ec_slot[c] = sl + 2u;
+        if (d.eq_blk)
+          for (uint32_t bq = 0; bq < nb; bq++)
+            if ((uint32_t)(qb >> 32) + bq < d.eq_blk_cap) d.eq_blk[(uint32_t)(qb >> 32) + bq] = sl;
       } else {
         d.ec_slot[c] = EC_NOLIST;
       }
@@ -221,9 +299,77 @@ __global__ __launch_bounds__(256) void k_ec_slots(PftDev d) {
   }
 }
 
+// ---- a wave over the points of many row segments ----
+// A lane per row with its own loop over the row's points leaves the wave waiting for its longest row, one dependent
+// load after the other.  Instead: the lanes fetch the segments' [start, end) (all loads of a round in flight), a prefix
+// sum over the lengths lays the points out in one flat index space, and the lanes walk THAT, 64 points per round; a
+// point's segment is found by binary search in the prefix array (LDS).  `seg(e, s0, s1)` yields segment e (s0 >= s1:
+// empty), `pt(pos)` is called once per point; both by all lanes of the wave.
+#define EC_SEGS 512
+struct SegScratch {
+  uint32_t s0[EC_SEGS], pre[EC_SEGS + 1];
+};
+template <class SegF, class PtF>
+__device__ __forceinline__ void wave_segments_points(SegScratch& S, int nseg, SegF&& seg, PtF&& pt) {
+  const int lane = lane_id();
+  for (int e0 = 0; e0 < nseg; e0 += EC_SEGS) {
+    const int n = min(EC_SEGS, nseg - e0);
+    for (int e = lane; e < n; e += WAVE) {
+      uint32_t a = 0, b = 0;
+      seg(e0 + e, a, b);
+      S.s0[e] = a;
+      S.pre[e] = b > a ? b - a : 0u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // exclusive prefix: a contiguous run of entries per lane, one wave scan
+    const int per = (n + WAVE - 1) / WAVE, a0 = min(n, lane * per), a1 = min(n, a0 + per);
+    uint32_t mine = 0;
+    for (int e = a0; e < a1; e++) mine += S.pre[e];
+    const uint32_t incl = wave_incl_scan(mine);
+    uint32_t run = incl - mine;
+    for (int e = a0; e < a1; e++) {
+      const uint32_t len = S.pre[e];
+      S.pre[e] = run;
+      run += len;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, WAVE - 1);
+    if (lane == 0) S.pre[n] = total;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i0 = 0; i0 < total; i0 += WAVE) {
+      const uint32_t i = i0 + (uint32_t)lane;
+      const bool live = i < total;
+      // the last entry e with pre[e] <= i (empty segments repeat a value: the LAST of them is the one with points)
+      int lo = 0, hi = n - 1;
+      const uint32_t ii = live ? i : 0u;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (S.pre[mid] <= ii)
+          lo = mid;
+        else
+          hi = mid - 1;
+      }
+      pt(live, S.s0[lo] + (ii - S.pre[lo]));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// -DPFT_EC_TIMING: per-phase wave time of k_ec_build (100 MHz ticks, summed over the waves) in PftHeader::dbg[16..]
+#ifdef PFT_EC_TIMING
+#define EC_TICK(k) do { const unsigned long long now_ = wall_clock64(); if (lane == 0) atomicAdd(&d.hdr->dbg[16 + (k)], now_ - tick_); tick_ = now_; } while (0)
+#else
+#define EC_TICK(k) do { } while (0)
+#endif
+
 // one wave per list: D, then the points within min(D + 2r, gate + r) of the cell centre
+#define EC_STAGE 448u  // staged candidates per wave (28 KiB for the four waves)
 __global__ __launch_bounds__(256) void k_ec_build(PftParams prm, PftDev d) {
   __shared__ uint32_t wcnt[4];
+  __shared__ float4 stage[4][EC_STAGE];
+  __shared__ SegScratch segs[4];
   const PftHeader* h = d.hdr;
   const uint32_t ns = min(h->ec_nslots, (uint32_t)PFT_EC_SLOTS);
   const float g = h->eg_g, inv_g = h->eg_inv_g, hh = 0.5f * h->eg_g;
@@ -237,12 +383,30 @@ __global__ __launch_bounds__(256) void k_ec_build(PftParams prm, PftDev d) {
     const uint32_t c = d.ec_cells[s];
     const int cx = (int)(c % (uint32_t)dx_), cy = (int)((c / (uint32_t)dx_) % (uint32_t)dy_),
               cz = (int)(c / (uint32_t)(dx_ * dy_));
+#ifdef PFT_EC_TIMING
+    unsigned long long tick_ = wall_clock64();
+#endif
     const float mx = h->eg_min[0] + ((float)cx + 0.5f) * g, my = h->eg_min[1] + ((float)cy + 0.5f) * g,
                 mz = h->eg_min[2] + ((float)cz + 0.5f) * g;
-    // ---- D: shells of rows around the cell, lanes over rows ----
+    // ---- D: shells of rows around the cell, lanes over rows.  The first three shells one by one (most cells with a
+    // list find their nearest point there); what is left of the cube that holds everything within gate + r of the
+    // centre is then searched in one sweep -- a chain of seven dependent shells was most of this kernel's time ----
     float best = INFINITY;
-    bool none = false;
-    for (int k = 0; k <= Kmax; k++) {
+    bool none = false, found = false;
+    // squared distance from the centre to the points [s0, s1) of the cell-sorted cloud, four loads in flight
+    auto scan_points = [&](uint32_t s0, uint32_t s1) {
+      for (uint32_t pos = s0; pos < s1; pos += 4u) {
+        const float4 p0 = d.leaf_pts[pos], p1 = d.leaf_pts[min(pos + 1u, s1 - 1u)], p2 = d.leaf_pts[min(pos + 2u, s1 - 1u)],
+                     p3 = d.leaf_pts[min(pos + 3u, s1 - 1u)];
+        const float a0 = (p0.x - mx) * (p0.x - mx) + ((p0.y - my) * (p0.y - my) + (p0.z - mz) * (p0.z - mz));
+        const float a1 = (p1.x - mx) * (p1.x - mx) + ((p1.y - my) * (p1.y - my) + (p1.z - mz) * (p1.z - mz));
+        const float a2 = (p2.x - mx) * (p2.x - mx) + ((p2.y - my) * (p2.y - my) + (p2.z - mz) * (p2.z - mz));
+        const float a3 = (p3.x - mx) * (p3.x - mx) + ((p3.y - my) * (p3.y - my) + (p3.z - mz) * (p3.z - mz));
+        best = fminf(best, fminf(fminf(a0, a1), fminf(a2, a3)));
+      }
+    };
+    const int KA = min(2, Kmax);
+    for (int k = 0; k <= KA; k++) {
       const int side = 2 * k + 1;
       for (int t = lane; t < side * side; t += WAVE) {
         const int oz = t / side - k, oy = t % side - k;
@@ -259,55 +423,109 @@ __global__ __launch_bounds__(256) void k_ec_build(PftParams prm, PftDev d) {
             x0 = x1 = sg == 0 ? cx - k : cx + k;
             if (x0 < 0 || x0 >= dx_) continue;
           }
-          const uint32_t s0 = d.eg_start[row + (uint32_t)x0], s1 = d.eg_start[row + (uint32_t)x1 + 1u];
-          for (uint32_t pos = s0; pos < s1; pos++) {
-            const float4 p = d.leaf_pts[pos];
-            const float ex = p.x - mx, ey = p.y - my, ez = p.z - mz;
-            best = fminf(best, ex * ex + (ey * ey + ez * ez));
-          }
+          if (x0 > x1) continue;
+          scan_points(d.eg_start[row + (uint32_t)x0], d.eg_start[row + (uint32_t)x1 + 1u]);
         }
       }
       const float wb = wave_min(best);
       const float reach = (float)k * g + hh;  // every point not seen yet is at least this far from the centre
-      if (wb <= reach * reach * 0.999f) break;
+      if (wb <= reach * reach * 0.999f) {
+        found = true;
+        break;
+      }
       if (reach - r > gate) {  // no query of this cell has a neighbour inside the gate
         none = true;
         break;
       }
     }
+    EC_TICK(0);
+    // what is left of the cube of Kmax cells in two sweeps (up to 4 cells, then the rest): a sweep visits every point of
+    // its cube shell, and the whole visible surface of the object lies inside the last one
+    for (int kin = KA, kout = min(4, Kmax); !found && !none && kin < Kmax; kin = kout, kout = Kmax) {
+      const int side = 2 * kout + 1;
+      wave_segments_points(
+          segs[w], 2 * side * side,
+          [&](int e, uint32_t& a, uint32_t& bnd) {  // two segments per row: left and right of the part seen before
+            const int t = e >> 1, sg = e & 1;
+            const int oz = t / side - kout, oy = t % side - kout;
+            const int z = cz + oz, y = cy + oy;
+            if (z < 0 || z >= dz_ || y < 0 || y >= dy_) return;
+            const bool inner = abs(oz) <= kin && abs(oy) <= kin;  // the middle of this row was seen before
+            int x0 = cx - kout, x1 = cx + kout;
+            if (inner) {
+              if (sg == 0)
+                x1 = cx - kin - 1;
+              else
+                x0 = cx + kin + 1;
+            } else if (sg == 1) {
+              return;
+            }
+            x0 = max(x0, 0);
+            x1 = min(x1, dx_ - 1);
+            if (x0 > x1) return;
+            const uint32_t row = (uint32_t)((z * dy_ + y) * dx_);
+            a = d.eg_start[row + (uint32_t)x0];
+            bnd = d.eg_start[row + (uint32_t)x1 + 1u];
+          },
+          [&](bool live, uint32_t pos) {
+            if (!live) return;
+            const float4 p = d.leaf_pts[pos];
+            best = fminf(best, (p.x - mx) * (p.x - mx) + ((p.y - my) * (p.y - my) + (p.z - mz) * (p.z - mz)));
+          });
+      const float wb = wave_min(best);
+      const float reach = (float)kout * g + hh;  // every point not seen yet is at least this far from the centre
+      if (wb <= reach * reach * 0.999f) found = true;
+      // (after the last sweep everything within Kmax * g + hh >= gate + r of the centre has been seen)
+    }
+    EC_TICK(1);
     const float D = sqrtf(wave_min(best));
     if (none || !(D - r <= gate)) {
       if (lane == 0) d.ec_count[s] = 0u;
+      EC_TICK(4);
       continue;
     }
     const float T = fminf(D + 2.0f * r, gate + r) + 1.0e-4f, T2 = T * T;
-    // ---- the list: rows within T of the centre, lanes over rows; counted first, then allotted in the pool, then written ----
+    // ---- the list: rows within T of the centre, lanes over rows.  One walk: the candidates are staged in LDS (and
+    // counted), then allotted in the pool and copied out; a list longer than the staging area is walked a second time ----
     const int KT = (int)ceilf((T + hh) * inv_g), side = 2 * KT + 1;
     uint32_t total = 0, base = 0;
+    if (lane == 0) wcnt[w] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     for (int pass = 0; pass < 2; pass++) {
-      uint32_t mine = 0;
-      for (int t = lane; t < side * side; t += WAVE) {
-        const int oz = t / side - KT, oy = t % side - KT;
-        const int z = cz + oz, y = cy + oy;
-        if (z < 0 || z >= dz_ || y < 0 || y >= dy_) continue;
-        const float lz = fmaxf((float)abs(oz) * g - hh, 0.0f) * 0.9999f, ly = fmaxf((float)abs(oy) * g - hh, 0.0f) * 0.9999f;
-        const float lyz = ly * ly + lz * lz;
-        if (lyz > T2) continue;
-        const int kx = (int)floorf((sqrtf(T2 - lyz) + hh) * inv_g) + 1;
-        const int x0 = max(cx - kx, 0), x1 = min(cx + kx, dx_ - 1);
-        const uint32_t row = (uint32_t)((z * dy_ + y) * dx_);
-        const uint32_t s0 = d.eg_start[row + (uint32_t)x0], s1 = d.eg_start[row + (uint32_t)x1 + 1u];
-        for (uint32_t pos = s0; pos < s1; pos++) {
-          const float4 p = d.leaf_pts[pos];
-          const float ex = p.x - mx, ey = p.y - my, ez = p.z - mz;
-          if (ex * ex + (ey * ey + ez * ez) <= T2) {
-            if (pass == 1) d.ec_list[base + atomicAdd(&wcnt[w], 1u)] = make_float4(p.x, p.y, p.z, __uint_as_float(pos));
-            mine++;
-          }
-        }
-      }
+      wave_segments_points(
+          segs[w], side * side,
+          [&](int t, uint32_t& a, uint32_t& bnd) {
+            const int oz = t / side - KT, oy = t % side - KT;
+            const int z = cz + oz, y = cy + oy;
+            if (z < 0 || z >= dz_ || y < 0 || y >= dy_) return;
+            const float lz = fmaxf((float)abs(oz) * g - hh, 0.0f) * 0.9999f, ly = fmaxf((float)abs(oy) * g - hh, 0.0f) * 0.9999f;
+            const float lyz = ly * ly + lz * lz;
+            if (lyz > T2) return;
+            const int kx = (int)floorf((sqrtf(T2 - lyz) + hh) * inv_g) + 1;
+            const int x0 = max(cx - kx, 0), x1 = min(cx + kx, dx_ - 1);
+            const uint32_t row = (uint32_t)((z * dy_ + y) * dx_);
+            a = d.eg_start[row + (uint32_t)x0];
+            bnd = d.eg_start[row + (uint32_t)x1 + 1u];
+          },
+          [&](bool live, uint32_t pos) {
+            if (!live) return;
+            const float4 p = d.leaf_pts[pos];
+            const float ex = p.x - mx, ey = p.y - my, ez = p.z - mz;
+            if (ex * ex + (ey * ey + ez * ez) <= T2) {
+              const uint32_t k = atomicAdd(&wcnt[w], 1u);
+              const float4 e = make_float4(p.x, p.y, p.z, __uint_as_float(pos));
+              if (pass == 1)
+                d.ec_list[base + k] = e;
+              else if (k < EC_STAGE)
+                stage[w][k] = e;
+            }
+          });
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      EC_TICK(2);
       if (pass == 0) {
-        total = wave_sum(mine);
+        total = wcnt[w];
         if (lane == 0) {
           base = atomicAdd(&d.hdr->ec_pool_used, total);
           wcnt[w] = 0u;
@@ -319,12 +537,17 @@ __global__ __launch_bounds__(256) void k_ec_build(PftParams prm, PftDev d) {
           total = EC_NOLIST;
           break;
         }
+        if (total <= EC_STAGE) {  // (wave-uniform) the usual case: copy the staged entries out
+          for (uint32_t k = (uint32_t)lane; k < total; k += WAVE) d.ec_list[base + k] = stage[w][k];
+          break;
+        }
       }
     }
     if (lane == 0) {
       d.ec_count[s] = total;
       d.ec_base[s] = base;
     }
+    EC_TICK(3);
   }
 }
 
@@ -393,6 +616,41 @@ __device__ void eg_shell_search(const PftDev& d, int cqx, int cqy, int cqz, floa
 }
 
 // ---- A7 with the exact nearest neighbour ----
+struct CohParams {
+  double wd, whsv, maxd2;
+  float hw, sw, vw;
+};
+
+// DistanceCoherence x HSVColorCoherence of one pair (A7a, A7b, as in pft_likelihood.hip); 0 when the query has no
+// neighbour inside the gate.  bt = the neighbour's record {x, y, z, packed hsv}, j = the reference point's position.
+__device__ __forceinline__ double exact_pair_value(const PftDev& d, const CohParams& cp, const float* lut_h,
+                                                   const float* lut_s, float qx, float qy, float qz, float best,
+                                                   uint32_t bi, const float4& bt, uint32_t j) {
+  if (!(bi != 0xffffffffu && (double)best < cp.maxd2)) return 0.0;
+  const float ex = qx - bt.x, ey = qy - bt.y, ez = qz - bt.z;
+  const float n2 = (ex * ex + ey * ey) + ez * ez;
+  const double dist = (double)sqrt_rn_coherence(n2);
+  const double A = 1.0 + dist * dist * cp.wd;
+  const float4 rh = d.ref_hsv[j];
+  const uint32_t pk = __float_as_uint(bt.w);
+  const float th = lut_h[pk & 0xffu], ts = lut_s[(pk >> 8) & 0xffu], tv = lut_s[(pk >> 16) & 0xffu];
+  const float hd1 = fabsf(rh.x - th);
+  float hd2;
+  if (rh.x < th)
+    hd2 = fabsf(1.0f + rh.x - th);
+  else
+    hd2 = fabsf(1.0f + th - rh.x);
+  float h_diff;
+  if (hd1 < hd2)
+    h_diff = cp.hw * hd1 * hd1;
+  else
+    h_diff = cp.hw * hd2 * hd2;
+  const float s_diff = cp.sw * (rh.y - ts) * (rh.y - ts);
+  const float v_diff = cp.vw * (rh.z - tv) * (rh.z - tv);
+  const double Bq = 1.0 + cp.whsv * (double)(h_diff + s_diff + v_diff);
+  return 1.0 / (A * Bq);
+}
+
 template <bool DEBUG_NN>
 __global__ __launch_bounds__(256) void k_likelihood_exact(PftParams prm, PftDev d, uint32_t n_particles, int use_lists) {
   __shared__ float lut_h[256], lut_s[256];
@@ -413,8 +671,7 @@ __global__ __launch_bounds__(256) void k_likelihood_exact(PftParams prm, PftDev 
   const double maxd2 = prm.maxd2;
   const float gate_f = (float)maxd2 * 1.0001f;  // pruning bound; the gate itself is the double comparison below
   const int R = (int)ceilf(sqrtf((float)maxd2) * inv_g) + 1;
-  const double wd = prm.dist_w, whsv = prm.hsv_w;
-  const float hw = prm.h_w, sw = prm.s_w, vw = prm.v_w;
+  const CohParams cp = {prm.dist_w, prm.hsv_w, maxd2, prm.h_w, prm.s_w, prm.v_w};
   const uint32_t M = prm.M, nchunk = prm.nchunk;
   const int lane = lane_id(), nw = blockDim.x >> 6;
   const uint32_t n_items = n_particles * nchunk;
@@ -510,31 +767,7 @@ __global__ __launch_bounds__(256) void k_likelihood_exact(PftParams prm, PftDev 
         d.nn_idx[o] = in_gate ? (int32_t)bi : -1;  // neighbours outside the gate are not searched for
         d.nn_d2[o] = in_gate ? best : INFINITY;
       }
-      if (bi != 0xffffffffu && (double)best < maxd2) {
-        // DistanceCoherence x HSVColorCoherence: as in pft_likelihood.hip (A7a, A7b)
-        const float ex = qx - bt.x, ey = qy - bt.y, ez = qz - bt.z;
-        const float n2 = (ex * ex + ey * ey) + ez * ez;
-        const double dist = (double)sqrt_rn_coherence(n2);
-        const double A = 1.0 + dist * dist * wd;
-        const float4 rh = d.ref_hsv[j];
-        const uint32_t pk = __float_as_uint(bt.w);
-        const float th = lut_h[pk & 0xffu], ts = lut_s[(pk >> 8) & 0xffu], tv = lut_s[(pk >> 16) & 0xffu];
-        const float hd1 = fabsf(rh.x - th);
-        float hd2;
-        if (rh.x < th)
-          hd2 = fabsf(1.0f + rh.x - th);
-        else
-          hd2 = fabsf(1.0f + th - rh.x);
-        float h_diff;
-        if (hd1 < hd2)
-          h_diff = hw * hd1 * hd1;
-        else
-          h_diff = hw * hd2 * hd2;
-        const float s_diff = sw * (rh.y - ts) * (rh.y - ts);
-        const float v_diff = vw * (rh.z - tv) * (rh.z - tv);
-        const double Bq = 1.0 + whsv * (double)(h_diff + s_diff + v_diff);
-        val += 1.0 / (A * Bq);
-      }
+      val += exact_pair_value(d, cp, lut_h, lut_s, qx, qy, qz, best, bi, bt, j);
     }
     val = wave_sum(val);
     if (lane == 0) d.partial[(size_t)pi * nchunk + ch] = val;
@@ -544,17 +777,261 @@ __global__ __launch_bounds__(256) void k_likelihood_exact(PftParams prm, PftDev 
   }
 }
 
+
+// ---- the same search with the queries sorted by grid cell ----
+// k_likelihood_exact above walks a list per LANE: 64 lanes, some 40 different lists, every candidate a divergent
+// 16-byte gather -- the kernel is bound by those gathers, not by arithmetic.  Sorted by cell, 64 queries of ONE cell
+// share a wave: the candidate is wave-uniform (scalar loads), a test is a dozen VALU instructions and no memory
+// instruction.  k_ec_mark has counted the queries per cell, k_ec_slots has given every such cell a segment of the sorted
+// array and its 64-query blocks, k_eq_scatter writes {q, id} into the segments (order inside a segment is
+// irrelevant: a query's result goes to out[id]), k_eq_search is one wave per block, k_eq_reduce sums out[] per
+// (particle, chunk) in the order of the per-query kernel -- the two paths give the same bits.
+
+template <bool DEBUG_NN>
+__device__ __forceinline__ void eq_finish(const PftDev& d, const CohParams& cp, const float* lut_h, const float* lut_s,
+                                          uint32_t M, uint32_t id, float qx, float qy, float qz, float best, uint32_t bi,
+                                          const float4& bt) {
+  const uint32_t pi = id / M, j = id - pi * M;
+  if (DEBUG_NN) {
+    const size_t o = (size_t)pi * M + d.ref_perm[j];
+    const bool in_gate = bi != 0xffffffffu && (double)best < cp.maxd2;
+    d.nn_idx[o] = in_gate ? (int32_t)bi : -1;  // neighbours outside the gate are not searched for
+    d.nn_d2[o] = in_gate ? best : INFINITY;
+  }
+  d.eq_out[id] = exact_pair_value(d, cp, lut_h, lut_s, qx, qy, qz, best, bi, bt, j);
+}
+
+// every query goes into its cell's segment -- or is answered on the spot: no cloud, a cell whose list is empty (no
+// neighbour inside the gate for any of its queries), or no list at all (outside the grid, pool full: shell search).
+// A workgroup counts its tile per cell in LDS as k_ec_mark does, reserves a piece of each cell's segment with ONE global
+// atomic, and hands out the positions inside the piece with LDS atomics.
+#define EQ_INLINE_EMPTY 0xfffffffeu
+#define EQ_INLINE_SHELL 0xffffffffu
+template <bool DEBUG_NN>
+__global__ __launch_bounds__(1024) void k_eq_scatter(PftParams prm, PftDev d, uint32_t n_particles, uint32_t ppw) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t eq_lds[];
+  uint32_t* key = eq_lds;
+  uint32_t* val = eq_lds + EQ_TAB;
+  float* lut_h = reinterpret_cast<float*>(eq_lds + 2u * EQ_TAB);
+  float* lut_s = lut_h + 256;
+  const PftHeader* h = d.hdr;
+  if (d.p_active) n_particles = *d.p_active;
+  const uint32_t p0 = min(n_particles, blockIdx.x * ppw), p1 = min(n_particles, p0 + ppw);
+  if (p0 >= p1) return;
+  for (uint32_t e = threadIdx.x; e < EQ_TAB; e += blockDim.x) {
+    key[e] = EQ_EMPTY;
+    val[e] = 0u;
+  }
+  for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
+    lut_h[i] = (float)i / 180.0f;
+    lut_s[i] = (float)i / 255.0f;
+  }
+  __syncthreads();
+  const uint32_t n_crop = h->n_crop;
+  const float g = h->eg_g, inv_g = h->eg_inv_g;
+  const int dx_ = h->eg_dim[0], dy_ = h->eg_dim[1], dz_ = h->eg_dim[2];
+  const float gate_f = (float)prm.maxd2 * 1.0001f;
+  const int R = (int)ceilf(sqrtf((float)prm.maxd2) * inv_g) + 1;
+  const CohParams cp = {prm.dist_w, prm.hsv_w, prm.maxd2, prm.h_w, prm.s_w, prm.v_w};
+  const uint32_t M = prm.M;
+  // where a cell's queries go: a segment position, or one of the two answers on the spot
+  auto route_of_cell = [&](uint32_t c, uint32_t& slot) -> uint32_t {
+    const uint32_t sl = d.ec_slot[c];
+    if (sl < 2u || sl == EC_NOLIST) return EQ_INLINE_SHELL;
+    slot = sl - 2u;
+    const uint32_t cnt = d.ec_count[slot];
+    return cnt == EC_NOLIST ? EQ_INLINE_SHELL : (cnt == 0u ? EQ_INLINE_EMPTY : 0u);
+  };
+  if (n_crop > 0) {
+    eq_tile_queries(prm, d, p0, p1, [&](uint32_t, uint32_t, float qx, float qy, float qz) {
+      int cx, cy, cz;
+      if (!eg_query_cell(h, qx, qy, qz, cx, cy, cz)) return;
+      const uint32_t e = eq_insert(key, (uint32_t)((cz * dy_ + cy) * dx_ + cx));
+      if (e < EQ_TAB) atomicAdd(&val[e], 1u);
+    });
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < EQ_TAB; e += blockDim.x) {
+      if (key[e] == EQ_EMPTY) continue;
+      uint32_t slot = 0;
+      const uint32_t route = route_of_cell(key[e], slot);
+      val[e] = route ? route : d.eq_qbase[slot] + atomicAdd(&d.eq_fill[slot], val[e]);
+    }
+    __syncthreads();
+  }
+  eq_tile_queries(prm, d, p0, p1, [&](uint32_t pi, uint32_t j, float qx, float qy, float qz) {
+    const uint32_t id = pi * M + j;
+    EgHit b;
+    b.best = INFINITY;
+    b.bi = 0xffffffffu;
+    b.bt = make_float4(0, 0, 0, 0);
+    if (n_crop > 0) {
+      int cqx, cqy, cqz;
+      uint32_t route = EQ_INLINE_SHELL, pos = 0;
+      if (eg_query_cell(h, qx, qy, qz, cqx, cqy, cqz)) {
+        const uint32_t c = (uint32_t)((cqz * dy_ + cqy) * dx_ + cqx);
+        const uint32_t e = eq_find(key, c);
+        if (e < EQ_TAB) {
+          route = val[e];
+          if (route < EQ_INLINE_EMPTY) pos = atomicAdd(&val[e], 1u);  // (positions stay far below the two sentinels: <= 2^30)
+        } else {  // a cell that found its probe window full: as without the table
+          uint32_t slot = 0;
+          route = route_of_cell(c, slot);
+          if (!route) pos = d.eq_qbase[slot] + atomicAdd(&d.eq_fill[slot], 1u);
+        }
+      }
+      if (route < EQ_INLINE_EMPTY) {
+        if (pos < d.eq_cap) d.eq_sorted[pos] = make_float4(qx, qy, qz, __uint_as_float(id));
+        return;
+      }
+      if (route == EQ_INLINE_SHELL) eg_shell_search(d, cqx, cqy, cqz, g, dx_, dy_, dz_, R, gate_f, qx, qy, qz, b);
+    }
+    eq_finish<DEBUG_NN>(d, cp, lut_h, lut_s, M, id, qx, qy, qz, b.best, b.bi, b.bt);
+  });
+}
+
+typedef float __attribute__((ext_vector_type(4))) eq_f4;
+typedef const __attribute__((address_space(4))) eq_f4* eq_const_list;  // wave-uniform address: scalar loads
+
+// one wave per block of 64 queries of one cell
+template <bool DEBUG_NN>
+__global__ __launch_bounds__(256) void k_eq_search(PftParams prm, PftDev d) {
+  __shared__ float lut_h[256], lut_s[256];
+  const PftHeader* h = d.hdr;
+  for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
+    lut_h[i] = (float)i / 180.0f;
+    lut_s[i] = (float)i / 255.0f;
+  }
+  __syncthreads();
+  const uint32_t nb = min((uint32_t)(h->eq_totals >> 32), d.eq_blk_cap);
+  const CohParams cp = {prm.dist_w, prm.hsv_w, prm.maxd2, prm.h_w, prm.s_w, prm.v_w};
+  const uint32_t M = prm.M;
+  const uint32_t lane = (uint32_t)lane_id(), nw = blockDim.x >> 6;
+  const uint32_t gw = blockIdx.x * nw + wave_id(), tw = gridDim.x * nw;
+  for (uint32_t bv = gw; bv < nb; bv += tw) {
+    const uint32_t blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv);
+    const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.eq_blk[blk]);
+    const uint32_t j0 = (blk - d.eq_bbase[slot]) * 64u, nq = d.eq_nq[slot];
+    const uint32_t n = min(64u, nq - j0);
+    const uint32_t cnt = d.ec_count[slot];
+    if (cnt == EC_NOLIST || cnt == 0u) continue;  // (uniform) these cells' queries were answered by k_eq_scatter
+    const eq_const_list list = (eq_const_list)(uintptr_t)(d.ec_list + d.ec_base[slot]);
+    const bool live = lane < n;
+    const float4 rec = d.eq_sorted[min((uint32_t)(d.eq_qbase[slot] + j0 + (live ? lane : 0u)), d.eq_cap - 1u)];
+    const float qx = rec.x, qy = rec.y, qz = rec.z;
+    float best = INFINITY;
+    uint32_t bpos = 0xffffffffu;
+    bool tie = false;  // some candidate was exactly as far as the best before it: settled after the loop
+#define EQ_TEST(C)                                                  \
+  {                                                                 \
+    const float ex = (C).x - qx, ey = (C).y - qy, ez = (C).z - qz;  \
+    const float dd = ex * ex + (ey * ey + ez * ez); /* pointSquaredDist */ \
+    tie |= dd == best;                                              \
+    const bool lt = dd < best;                                      \
+    best = lt ? dd : best;                                          \
+    bpos = lt ? __float_as_uint((C).w) : bpos;                      \
+  }
+    uint32_t k = 0;
+    for (; k + 4u <= cnt; k += 4u) {  // four scalar loads in flight
+      const eq_f4 c0 = list[k], c1 = list[k + 1u], c2 = list[k + 2u], c3 = list[k + 3u];
+      EQ_TEST(c0);
+      EQ_TEST(c1);
+      EQ_TEST(c2);
+      EQ_TEST(c3);
+    }
+    for (; k < cnt; k++) {
+      const eq_f4 c = list[k];
+      EQ_TEST(c);
+    }
+#undef EQ_TEST
+    if (tie) {  // equal distances (rare): among the candidates at the minimum, the lowest cloud index
+      uint32_t bidx = d.leaf_order[bpos];
+      for (uint32_t kk = 0; kk < cnt; kk++) {
+        const eq_f4 c = list[kk];
+        const float ex = c.x - qx, ey = c.y - qy, ez = c.z - qz;
+        const float dd = ex * ex + (ey * ey + ez * ez);
+        if (dd == best) {
+          const uint32_t pos = __float_as_uint(c.w), idx = d.leaf_order[pos];
+          if (idx < bidx) {
+            bidx = idx;
+            bpos = pos;
+          }
+        }
+      }
+    }
+    if (live) {
+      uint32_t bi = 0xffffffffu;
+      float4 bt = make_float4(0, 0, 0, 0);
+      if (bpos != 0xffffffffu) {
+        bi = d.leaf_order[bpos];
+        bt = d.leaf_pts[bpos];
+      }
+      eq_finish<DEBUG_NN>(d, cp, lut_h, lut_s, M, __float_as_uint(rec.w), qx, qy, qz, best, bi, bt);
+    }
+  }
+}
+
+// partial[particle][chunk] = the sum of its queries' values, lane by lane and then across the wave exactly as
+// k_likelihood_exact accumulates them
+__global__ __launch_bounds__(256) void k_eq_reduce(PftParams prm, PftDev d, uint32_t n_particles) {
+  const PftHeader* h = d.hdr;
+  if (d.p_active) n_particles = *d.p_active;
+  if (h->error && blockIdx.x == 0 && threadIdx.x == 0 && d.host_stat) {  // as k_likelihood: surfaced at the next host sync
+    d.host_stat[2] = h->error;
+    d.host_stat[3] |= h->error;
+  }
+  const uint32_t M = prm.M, nchunk = prm.nchunk;
+  const uint32_t lane = (uint32_t)lane_id(), nw = blockDim.x >> 6;
+  const uint32_t gw = blockIdx.x * nw + wave_id(), tw = gridDim.x * nw;
+  const uint32_t n_items = n_particles * nchunk;
+  for (uint32_t item = gw; item < n_items; item += tw) {
+    const uint32_t pi = item / nchunk, ch = item % nchunk;
+    double val = 0.0;
+    const uint32_t jend = min(M, (ch + 1u) * prm.ref_chunk);
+    for (uint32_t j = ch * prm.ref_chunk + lane; j < jend; j += WAVE) {
+      const double v = d.eq_out[(size_t)pi * M + j];
+      if (v != 0.0) val += v;  // (the per-query kernel adds only the pairs inside the gate)
+    }
+    val = wave_sum(val);
+    if (lane == 0) d.partial[(size_t)pi * nchunk + ch] = val;
+  }
+}
+
 void pftk_likelihood_exact(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, bool debug_nn,
                            int num_cus) {
   const int use_lists = getenv("PFT_EXACT_SHELLS_ONLY") ? 0 : 1;  // 0: the per-query shell search alone (cross-check, A/B timing)
+  // 1: a list walk per lane instead of the cell-sorted search (cross-check -- identical bits --, A/B timing)
+  const bool per_query = getenv("PFT_EXACT_PER_QUERY") != nullptr;
   const uint32_t items = n_particles * p.nchunk;
   uint32_t grid = 8u * (uint32_t)num_cus;
   const uint32_t need = (items + 3u) / 4u;
   if (grid > need) grid = need ? need : 1u;
+  // tiles of the LDS-aggregated passes: one workgroup per `ppw` particles
+  static bool attr_set[PFT_MAX_DEVICES];
+  const uint32_t tile_lds = 2u * EQ_TAB * 4u + 2048u;
+  const int dev = pftk_cur_device();
+  if (!attr_set[dev])
+    attr_set[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ec_mark), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds) == hipSuccess &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eq_scatter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds) == hipSuccess &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eq_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds) == hipSuccess;
+  uint32_t ppw = (n_particles + (uint32_t)num_cus - 1u) / (uint32_t)num_cus;
+  ppw = ppw < 1u ? 1u : (ppw > 32u ? 32u : ppw);
+  const uint32_t tiles = (n_particles + ppw - 1u) / ppw ? (n_particles + ppw - 1u) / ppw : 1u;
   if (use_lists) {
-    hipLaunchKernelGGL(k_ec_mark, dim3(grid), dim3(256), 0, s, p, d, n_particles);
+    hipLaunchKernelGGL(k_ec_mark, dim3(tiles), dim3(1024), tile_lds, s, p, d, n_particles, ppw);
     hipLaunchKernelGGL(k_ec_slots, dim3(4u * (uint32_t)num_cus), dim3(256), 0, s, d);
     hipLaunchKernelGGL(k_ec_build, dim3(8u * (uint32_t)num_cus), dim3(256), 0, s, p, d);
+  }
+  const unsigned long long nq = (unsigned long long)n_particles * p.M;
+  if (use_lists && !per_query && d.eq_cap && nq <= d.eq_cap) {
+    if (debug_nn) {
+      hipLaunchKernelGGL(k_eq_scatter<true>, dim3(tiles), dim3(1024), tile_lds, s, p, d, n_particles, ppw);
+      hipLaunchKernelGGL(k_eq_search<true>, dim3(16u * (uint32_t)num_cus), dim3(256), 0, s, p, d);
+    } else {
+      hipLaunchKernelGGL(k_eq_scatter<false>, dim3(tiles), dim3(1024), tile_lds, s, p, d, n_particles, ppw);
+      hipLaunchKernelGGL(k_eq_search<false>, dim3(16u * (uint32_t)num_cus), dim3(256), 0, s, p, d);
+    }
+    hipLaunchKernelGGL(k_eq_reduce, dim3(grid), dim3(256), 0, s, p, d, n_particles);
+    return;
   }
   if (debug_nn)
     hipLaunchKernelGGL(k_likelihood_exact<true>, dim3(grid), dim3(256), 0, s, p, d, n_particles, use_lists);

@@ -101,6 +101,7 @@ struct PftHeader {  // lives in HBM; written by kernels, read by later kernels (
   uint32_t eg_ncells;
   uint32_t ec_nslots;           // exact-NN mode: grid cells hit by at least one query this iteration (candidate lists)
   uint32_t ec_pool_used;        // exact-NN mode: candidate entries allotted so far
+  unsigned long long eq_totals;  // exact-NN mode: (64-query blocks << 32) | queries of the cells allotted so far (k_ec_slots)
   uint32_t p_active;            // KLD variant: current particle_num_ (written by init / k_resample_kld)
   uint32_t kld_k;               // KLD variant: distinct bins of the last resample (diagnostic)
   unsigned long long stat_queries, stat_scanned;
@@ -155,6 +156,16 @@ struct PftDev {  // device pointers (host-side struct, passed by value)
   uint32_t* ec_count;        // exact-NN mode: [PFT_EC_SLOTS] candidates of the list (0xffffffff: the pool was full, no list)
   uint32_t* ec_base;         // exact-NN mode: [PFT_EC_SLOTS] first entry of the list in ec_list
   float4* ec_list;           // exact-NN mode: [PFT_EC_POOL] candidates {x, y, z, position in leaf_pts}
+  // exact-NN mode, queries sorted by grid cell (one wave then walks ONE candidate list for 64 queries):
+  uint32_t* eq_cellq;        // [eg_cap] queries per grid cell this iteration
+  uint32_t* eq_nq;           // [PFT_EC_SLOTS] queries of the slot's cell that are searched through its list
+  uint32_t* eq_qbase;        // [PFT_EC_SLOTS] first sorted query of the slot
+  uint32_t* eq_bbase;        // [PFT_EC_SLOTS] first 64-query block of the slot
+  uint32_t* eq_fill;         // [PFT_EC_SLOTS] fill cursor of the scatter
+  uint32_t* eq_blk;          // [eq_blk_cap] slot of every block
+  float4* eq_sorted;         // [eq_cap] {qx, qy, qz, query id = particle * M + reference position}
+  double* eq_out;            // [eq_cap] by query id: the point coherence of the pair (0: no neighbour inside the gate)
+  uint32_t eq_cap, eq_blk_cap;  // 0: the per-query kernel is used instead
   uint32_t* kld_table;       // KLD variant: open-addressing table of first occurrences, 2 x pow2(kld_max) entries
   int32_t* kld_bins;         // KLD variant: 6 ints per candidate
   uint32_t* host_stat;  // pinned host memory, device-visible: [0] last n_crop, [1] last octree depth (read by the

@@ -549,12 +549,18 @@ def test_crop_one_pass_and_two_pass_agree(gpu, orc, data, monkeypatch):
 
 
 # ---- NearestPairPointCloudCoherence (true nearest neighbour) -----------------------------------
-@pytest.mark.parametrize("M,N,P,maxd,shells", [(256, 6000, 48, 0.1, False), (513, 20000, 33, 0.1, False), (64, 900, 20, 0.03, False),
-                                               (300, 50000, 16, 0.25, False), (256, 6000, 48, 0.1, True), (300, 50000, 16, 0.25, True)])
-def test_exact_nearest_pair_coherence(gpu, orc, data, M, N, P, maxd, shells, monkeypatch):
-    """both search paths of pft_exact_nn.hip: per-cell candidate lists (default) and the per-query shell search alone"""
-    if shells:
-        monkeypatch.setenv("PFT_EXACT_SHELLS_ONLY", "1")
+EXACT_PATH_ENV = {"sorted": None, "per_query": "PFT_EXACT_PER_QUERY", "shells": "PFT_EXACT_SHELLS_ONLY"}
+
+
+@pytest.mark.parametrize("M,N,P,maxd,path", [(256, 6000, 48, 0.1, "sorted"), (513, 20000, 33, 0.1, "sorted"), (64, 900, 20, 0.03, "sorted"),
+                                             (300, 50000, 16, 0.25, "sorted"), (256, 6000, 48, 0.1, "per_query"),
+                                             (513, 20000, 33, 0.1, "per_query"), (300, 50000, 16, 0.25, "per_query"),
+                                             (256, 6000, 48, 0.1, "shells"), (300, 50000, 16, 0.25, "shells")])
+def test_exact_nearest_pair_coherence(gpu, orc, data, M, N, P, maxd, path, monkeypatch):
+    """the three search paths of pft_exact_nn.hip: per-cell candidate lists walked by waves of cell-sorted queries
+    (default), the same lists walked per query, and the per-query shell search alone"""
+    if EXACT_PATH_ENV[path]:
+        monkeypatch.setenv(EXACT_PATH_ENV[path], "1")
     model = scene.make_model(M, seed=900 + M)
     cloud = data["scene"][:N]
     o = orc.Tracker(orc.default_config(particle_num=P, threads=0, emulate_pcl_alloc=0, exact_nearest=1, max_distance=maxd))
@@ -600,6 +606,33 @@ def test_exact_nearest_pair_coherence(gpu, orc, data, M, N, P, maxd, shells, mon
         rg, ro = g2.getResult(), o2.get_result()
         for k in ("x", "y", "z", "roll", "pitch", "yaw"):
             assert abs(float(rg[k]) - float(ro[k])) < 1e-4, (f, k)
+
+
+def test_exact_nearest_sorted_and_per_query_paths_agree_bit_for_bit(gpu, data, monkeypatch):
+    """the cell-sorted search (one candidate list per wave) and the per-query list walk are the same arithmetic in the same
+    summation order: a tracking run at 1 024 particles ends in identical populations"""
+    out = []
+    for path in ("sorted", "per_query"):
+        if EXACT_PATH_ENV[path]:
+            monkeypatch.setenv(EXACT_PATH_ENV[path], "1")
+        g = gpu.ParticleFilterTracker(seed=3)
+        g.setParticleNum(1024)
+        coh = gpu.NearestPairPointCloudCoherence()
+        coh.addPointCoherence(gpu.DistanceCoherence())
+        hc = gpu.HSVColorCoherence()
+        hc.setWeight(0.1)
+        coh.addPointCoherence(hc)
+        coh.setMaximumDistance(0.1)
+        g.setCloudCoherence(coh)
+        g.setReferenceCloud(data["model"])
+        g.setTrans(scene.initial_trans())
+        g.setInputCloud(data["scene"])
+        for _ in range(4):
+            g.compute()
+        out.append((g.getParticles(), g.getResult()))
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    assert out[0][1] == out[1][1]
+    assert out[0][0]["weight"].max() > 1.2 / 1024
 
 
 def test_exact_nearest_edge_cases(gpu, orc, data):
@@ -688,9 +721,12 @@ def test_eval_weights_adversarial_clouds(gpu, orc, data, kind, monkeypatch):
 
 
 @pytest.mark.parametrize("kind", ["lattice", "duplicates"])
-def test_exact_nearest_ties_take_the_lowest_index(gpu, orc, data, kind):
+@pytest.mark.parametrize("path", ["sorted", "per_query"])
+def test_exact_nearest_ties_take_the_lowest_index(gpu, orc, data, kind, path, monkeypatch):
     """clouds with many equal distances (points on a 1 cm lattice, 40 positions repeated 150 times each): the true nearest
     neighbour is the lowest cloud index among the closest points, whatever order the grid cells hold them in"""
+    if EXACT_PATH_ENV[path]:
+        monkeypatch.setenv(EXACT_PATH_ENV[path], "1")
     rng = np.random.default_rng(11)
     gt = np.array(data["gt"][:3], np.float32)
     n = 6000

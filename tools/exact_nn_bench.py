@@ -40,6 +40,14 @@ for exact in (False, True):
     if exact:
         import ctypes as C
         import numpy as np
+        dbg = np.zeros(32, np.uint64)
+        t._check(t._L.pft_debug_get_descent_stats(t._h, dbg.ctypes.data_as(C.c_void_p)))
+        print("  last iteration: %d cropped points in a grid of %d cells; %d cells hold queries, %d list entries (%.1f per cell); %d queries in %d blocks of 64"
+              % (dbg[13], dbg[12], dbg[8], dbg[9], float(dbg[9]) / max(int(dbg[8]), 1), dbg[10], dbg[11]))
+        if dbg[16:21].any():  # a -DPFT_EC_TIMING build: where k_ec_build's waves spend their time (us summed over the waves of ALL launches)
+            print("  k_ec_build wave time (us): first shells %.0f, far sweeps %.0f, list walk %.0f, allot + copy %.0f, no-list exit %.0f"
+                  % tuple(dbg[16:21].astype(float) / 100.0))
+        os.environ["PFT_EXACT_PER_QUERY"] = "1"  # the list statistics below are counted by the per-query kernel's debug variant
         p = t.getParticles()
         t.evalWeights(p, want_nn=True)  # the debug variant counts list use (first call: counters start at zero?)
         dbg = np.zeros(32, np.uint64)
