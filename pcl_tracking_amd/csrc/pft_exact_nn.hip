@@ -142,6 +142,23 @@ __global__ __launch_bounds__(256) void k_eg_scatter(PftDev d) {
   d.leaf_order[pos] = i;
 }
 
+// which grid rows (cells of one z, y) hold a point at all: the point cloud is a surface, most rows of a cell's
+// neighbourhood are empty, and one bit tells so without the two loads of the row's cell starts
+__global__ __launch_bounds__(256) void k_eg_rows(PftDev d) {
+  const PftHeader* h = d.hdr;
+  const uint32_t dx_ = (uint32_t)h->eg_dim[0], nrows = h->n_crop ? (uint32_t)(h->eg_dim[1] * h->eg_dim[2]) : 0u;
+  for (uint32_t r0 = blockIdx.x * 256u; r0 < nrows; r0 += gridDim.x * 256u) {
+    const uint32_t r = r0 + threadIdx.x;
+    const bool occ = r < nrows && d.eg_start[r * dx_ + dx_] != d.eg_start[r * dx_];
+    const unsigned long long m = __ballot(occ);
+    if ((lane_id() & 31) == 0 && r < nrows) d.eg_rowocc[r >> 5] = (uint32_t)(m >> (lane_id() & 32));
+  }
+}
+__device__ __forceinline__ bool eg_row_occupied(const PftDev& d, int z, int y, int dy_) {
+  const uint32_t r = (uint32_t)(z * dy_ + y);
+  return (d.eg_rowocc[r >> 5] >> (r & 31u)) & 1u;
+}
+
 void pftk_exact_grid(hipStream_t s, const PftParams& p, const PftDev& d) {
   const uint32_t ntiles = (d.eg_cap + EG_TILE - 1u) / EG_TILE;
   const uint32_t nb = (d.N + 255u) / 256u;
@@ -152,6 +169,7 @@ void pftk_exact_grid(hipStream_t s, const PftParams& p, const PftDev& d) {
   hipLaunchKernelGGL(k_eg_tscan, dim3(1), dim3(1024), 0, s, d);
   hipLaunchKernelGGL(k_eg_apply, dim3(ntiles), dim3(256), 0, s, d);
   hipLaunchKernelGGL(k_eg_scatter, dim3(nb ? nb : 1), dim3(256), 0, s, d);
+  hipLaunchKernelGGL(k_eg_rows, dim3(64), dim3(256), 0, s, d);
 }
 
 // ---- candidate lists ----
@@ -411,7 +429,7 @@ __global__ __launch_bounds__(256) void k_ec_build(PftParams prm, PftDev d) {
       for (int t = lane; t < side * side; t += WAVE) {
         const int oz = t / side - k, oy = t % side - k;
         const int z = cz + oz, y = cy + oy;
-        if (z < 0 || z >= dz_ || y < 0 || y >= dy_) continue;
+        if (z < 0 || z >= dz_ || y < 0 || y >= dy_ || !eg_row_occupied(d, z, y, dy_)) continue;
         const uint32_t row = (uint32_t)((z * dy_ + y) * dx_);
         const bool face = abs(oz) == k || abs(oy) == k;
         for (int sg = 0; sg < (face ? 1 : 2); sg++) {
@@ -449,7 +467,7 @@ __global__ __launch_bounds__(256) void k_ec_build(PftParams prm, PftDev d) {
             const int t = e >> 1, sg = e & 1;
             const int oz = t / side - kout, oy = t % side - kout;
             const int z = cz + oz, y = cy + oy;
-            if (z < 0 || z >= dz_ || y < 0 || y >= dy_) return;
+            if (z < 0 || z >= dz_ || y < 0 || y >= dy_ || !eg_row_occupied(d, z, y, dy_)) return;
             const bool inner = abs(oz) <= kin && abs(oy) <= kin;  // the middle of this row was seen before
             int x0 = cx - kout, x1 = cx + kout;
             if (inner) {
@@ -498,7 +516,7 @@ __global__ __launch_bounds__(256) void k_ec_build(PftParams prm, PftDev d) {
           [&](int t, uint32_t& a, uint32_t& bnd) {
             const int oz = t / side - KT, oy = t % side - KT;
             const int z = cz + oz, y = cy + oy;
-            if (z < 0 || z >= dz_ || y < 0 || y >= dy_) return;
+            if (z < 0 || z >= dz_ || y < 0 || y >= dy_ || !eg_row_occupied(d, z, y, dy_)) return;
             const float lz = fmaxf((float)abs(oz) * g - hh, 0.0f) * 0.9999f, ly = fmaxf((float)abs(oy) * g - hh, 0.0f) * 0.9999f;
             const float lyz = ly * ly + lz * lz;
             if (lyz > T2) return;

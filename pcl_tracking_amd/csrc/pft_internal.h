@@ -151,6 +151,7 @@ struct PftDev {  // device pointers (host-side struct, passed by value)
   uint32_t* eg_cnt;          // exact-NN mode: [eg_cap] cell counts / fill cursors
   uint32_t* eg_tile;         // exact-NN mode: per-2048-cell tile sums
   uint32_t eg_cap;           // exact-NN mode: cells available
+  uint32_t* eg_rowocc;       // exact-NN mode: [eg_cap / 32 + 1] bit (z * dim_y + y) = the grid row holds a point
   uint32_t* ec_slot;         // exact-NN mode: [eg_cap] 0 = no query in this cell, 1 = hit (before the slots are allotted), 0xffffffff = no list, else list slot + 2
   uint32_t* ec_cells;        // exact-NN mode: [PFT_EC_SLOTS] cell of every list slot
   uint32_t* ec_count;        // exact-NN mode: [PFT_EC_SLOTS] candidates of the list (0xffffffff: the pool was full, no list)
