@@ -70,7 +70,7 @@ struct pft_tracker {
   int32_t* d_alias_list = nullptr;
   double* d_alias_pref = nullptr;
   double* d_pop_part = nullptr;
-  uint32_t *d_eg_start = nullptr, *d_eg_cnt = nullptr, *d_eg_tile = nullptr, *d_eg_rowocc = nullptr;
+  uint32_t *d_eg_start = nullptr, *d_eg_cnt = nullptr, *d_eg_tile = nullptr;
   uint32_t *d_ec_slot = nullptr, *d_ec_cells = nullptr, *d_ec_count = nullptr, *d_ec_base = nullptr;
   float4* d_ec_list = nullptr;
   // exact-NN mode, cell-sorted queries (sized by the largest particle count x reference size evaluated so far)
@@ -347,7 +347,6 @@ static void sync_dev(pft_tracker* t) {
   d.eg_start = t->d_eg_start;
   d.eg_cnt = t->d_eg_cnt;
   d.eg_tile = t->d_eg_tile;
-  d.eg_rowocc = t->d_eg_rowocc;
   d.eg_cap = t->d_eg_start ? PFT_EG_CAP : 0u;
   d.ec_slot = t->d_ec_slot;
   d.ec_cells = t->d_ec_cells;
@@ -526,7 +525,6 @@ extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
     A(dalloc(&t->d_eg_start, (size_t)PFT_EG_CAP + 1));
     A(dalloc(&t->d_eg_cnt, (size_t)PFT_EG_CAP));
     A(dalloc(&t->d_eg_tile, (size_t)PFT_EG_CAP / 2048 + 2));
-    A(dalloc(&t->d_eg_rowocc, (size_t)PFT_EG_CAP / 32 + 2));
     A(dalloc(&t->d_ec_slot, (size_t)PFT_EG_CAP));
     A(dalloc(&t->d_ec_cells, (size_t)PFT_EC_SLOTS));
     A(dalloc(&t->d_ec_count, (size_t)PFT_EC_SLOTS));
@@ -589,7 +587,7 @@ extern "C" void pft_destroy(pft_tracker* t) {
   dfree(t->d_pt_key64); dfree(t->sort.keys[0]); dfree(t->sort.keys[1]); dfree(t->sort.vals[0]); dfree(t->sort.vals[1]);
   dfree(t->sort.hist); dfree(t->sort.tile_cnt); dfree(t->sort.tile_box); if (t->h_stat) hipHostFree(t->h_stat);
   dfree(t->d_partial); dfree(t->d_alias_list); dfree(t->d_alias_pos); dfree(t->d_raw_w);
-  dfree(t->d_alias_pref); dfree(t->d_pop_part); dfree(t->d_kld_table); dfree(t->d_kld_bins); dfree(t->d_eg_start); dfree(t->d_eg_cnt); dfree(t->d_eg_tile); dfree(t->d_eg_rowocc); dfree(t->d_ec_slot); dfree(t->d_ec_cells); dfree(t->d_ec_count); dfree(t->d_ec_base); dfree(t->d_ec_list); dfree(t->d_eq_cellq); dfree(t->d_eq_nq); dfree(t->d_eq_qbase); dfree(t->d_eq_bbase); dfree(t->d_eq_fill); dfree(t->d_eq_blk); dfree(t->d_eq_sorted); dfree(t->d_eq_out); dfree(t->d_hdr); dfree(t->d_nn_idx); dfree(t->d_nn_d2); dfree(t->d_dbg_part);
+  dfree(t->d_alias_pref); dfree(t->d_pop_part); dfree(t->d_kld_table); dfree(t->d_kld_bins); dfree(t->d_eg_start); dfree(t->d_eg_cnt); dfree(t->d_eg_tile); dfree(t->d_ec_slot); dfree(t->d_ec_cells); dfree(t->d_ec_count); dfree(t->d_ec_base); dfree(t->d_ec_list); dfree(t->d_eq_cellq); dfree(t->d_eq_nq); dfree(t->d_eq_qbase); dfree(t->d_eq_bbase); dfree(t->d_eq_fill); dfree(t->d_eq_blk); dfree(t->d_eq_sorted); dfree(t->d_eq_out); dfree(t->d_hdr); dfree(t->d_nn_idx); dfree(t->d_nn_d2); dfree(t->d_dbg_part);
   dfree(t->d_dbg_hdr); dfree(t->d_dbg_f);
   dfree(t->sv_part); dfree(t->sv_alias_list); dfree(t->sv_alias_pref); dfree(t->sv_alias_pos); dfree(t->sv_hdr);
   if (t->own_stream && t->stream) hipStreamDestroy(t->stream);

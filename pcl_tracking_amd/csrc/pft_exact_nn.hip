@@ -142,23 +142,6 @@ __global__ __launch_bounds__(256) void k_eg_scatter(PftDev d) {
   d.leaf_order[pos] = i;
 }
 
-// which grid rows (cells of one z, y) hold a point at all: the point cloud is a surface, most rows of a cell's
-// neighbourhood are empty, and one bit tells so without the two loads of the row's cell starts
-__global__ __launch_bounds__(256) void k_eg_rows(PftDev d) {
-  const PftHeader* h = d.hdr;
-  const uint32_t dx_ = (uint32_t)h->eg_dim[0], nrows = h->n_crop ? (uint32_t)(h->eg_dim[1] * h->eg_dim[2]) : 0u;
-  for (uint32_t r0 = blockIdx.x * 256u; r0 < nrows; r0 += gridDim.x * 256u) {
-    const uint32_t r = r0 + threadIdx.x;
-    const bool occ = r < nrows && d.eg_start[r * dx_ + dx_] != d.eg_start[r * dx_];
-    const unsigned long long m = __ballot(occ);
-    if ((lane_id() & 31) == 0 && r < nrows) d.eg_rowocc[r >> 5] = (uint32_t)(m >> (lane_id() & 32));
-  }
-}
-__device__ __forceinline__ bool eg_row_occupied(const PftDev& d, int z, int y, int dy_) {
-  const uint32_t r = (uint32_t)(z * dy_ + y);
-  return (d.eg_rowocc[r >> 5] >> (r & 31u)) & 1u;
-}
-
 void pftk_exact_grid(hipStream_t s, const PftParams& p, const PftDev& d) {
   const uint32_t ntiles = (d.eg_cap + EG_TILE - 1u) / EG_TILE;
   const uint32_t nb = (d.N + 255u) / 256u;
@@ -169,7 +152,6 @@ void pftk_exact_grid(hipStream_t s, const PftParams& p, const PftDev& d) {
   hipLaunchKernelGGL(k_eg_tscan, dim3(1), dim3(1024), 0, s, d);
   hipLaunchKernelGGL(k_eg_apply, dim3(ntiles), dim3(256), 0, s, d);
   hipLaunchKernelGGL(k_eg_scatter, dim3(nb ? nb : 1), dim3(256), 0, s, d);
-  hipLaunchKernelGGL(k_eg_rows, dim3(64), dim3(256), 0, s, d);
 }
 
 // ---- candidate lists ----
@@ -322,13 +304,13 @@ __global__ __launch_bounds__(256) void k_ec_slots(PftDev d) {
 // load after the other.  Instead: the lanes fetch the segments' [start, end) (all loads of a round in flight), a prefix
 // sum over the lengths lays the points out in one flat index space, and the lanes walk THAT, 64 points per round; a
 // point's segment is found by binary search in the prefix array (LDS).  `seg(e, s0, s1)` yields segment e (s0 >= s1:
-// empty), `pt(pos)` is called once per point; both by all lanes of the wave.
-#define EC_SEGS 512
+// empty), `pt4(live[4], pos[4])` takes four points per lane; both are called by all lanes of the wave.
+#define EC_SEGS 64
 struct SegScratch {
   uint32_t s0[EC_SEGS], pre[EC_SEGS + 1];
 };
 template <class SegF, class PtF>
-__device__ __forceinline__ void wave_segments_points(SegScratch& S, int nseg, SegF&& seg, PtF&& pt) {
+__device__ __forceinline__ void wave_segments_points(SegScratch& S, int nseg, SegF&& seg, PtF&& pt4) {
   const int lane = lane_id();
   for (int e0 = 0; e0 < nseg; e0 += EC_SEGS) {
     const int n = min(EC_SEGS, nseg - e0);
@@ -355,20 +337,24 @@ __device__ __forceinline__ void wave_segments_points(SegScratch& S, int nseg, Se
     if (lane == 0) S.pre[n] = total;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t i0 = 0; i0 < total; i0 += WAVE) {
-      const uint32_t i = i0 + (uint32_t)lane;
-      const bool live = i < total;
-      // the last entry e with pre[e] <= i (empty segments repeat a value: the LAST of them is the one with points)
-      int lo = 0, hi = n - 1;
-      const uint32_t ii = live ? i : 0u;
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (S.pre[mid] <= ii)
-          lo = mid;
-        else
-          hi = mid - 1;
+    // four points per lane and round, their searches and loads independent of one another (a round is a chain of LDS
+    // and memory latencies; the rounds of one wave do not overlap by themselves)
+    for (uint32_t i0 = 0; i0 < total; i0 += 4u * WAVE) {
+      uint32_t pos[4];
+      bool live[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t i = i0 + (uint32_t)(u * WAVE + lane);
+        live[u] = i < total;
+        const uint32_t ii = live[u] ? i : 0u;
+        // the last entry e with pre[e] <= i (empty segments repeat a value: the LAST of them is the one with points)
+        int lo = 0;
+#pragma unroll
+        for (int step = EC_SEGS / 2; step > 0; step >>= 1)
+          if (lo + step < n && S.pre[lo + step] <= ii) lo += step;
+        pos[u] = S.s0[lo] + (ii - S.pre[lo]);
       }
-      pt(live, S.s0[lo] + (ii - S.pre[lo]));
+      pt4(live, pos);
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -382,8 +368,15 @@ __device__ __forceinline__ void wave_segments_points(SegScratch& S, int nseg, Se
 #define EC_TICK(k) do { } while (0)
 #endif
 
-// one wave per list: D, then the points within min(D + 2r, gate + r) of the cell centre
+// one wave per list: D, then the points within min(D + 2r, gate + r) of the cell centre.
+// The cells are sorted (z, y, x)-major, so the cells of one z and a RANGE of y -- all x -- are one contiguous piece
+// of the sorted cloud: a neighbourhood of (2K + 1)^3 cells is 2K + 1 such slabs, two loads of cell starts each, and the
+// slabs' points are read with consecutive lanes on consecutive records.  A slab holds points outside the x range of the
+// neighbourhood too (the cloud is sparse: a few points per grid row), which the distance tests sort out; per-row
+// segments trimmed in x -- two scattered loads of cell starts per row, 225 rows around a cell -- were bound by the
+// cache-line throughput of their divergent loads (93 % of the wave cycles in s_waitcnt).
 #define EC_STAGE 448u  // staged candidates per wave (28 KiB for the four waves)
+#define EC_CHUNK 512u  // list-pool entries a wave takes at a time
 __global__ __launch_bounds__(256) void k_ec_build(PftParams prm, PftDev d) {
   __shared__ uint32_t wcnt[4];
   __shared__ float4 stage[4][EC_STAGE];
@@ -397,6 +390,8 @@ __global__ __launch_bounds__(256) void k_ec_build(PftParams prm, PftDev d) {
   const int lane = lane_id(), w = wave_id(), nw = blockDim.x >> 6;
   const uint32_t gw = blockIdx.x * nw + w, tw = gridDim.x * nw;
   const int Kmax = (int)ceilf((gate + r) * inv_g) + 1;
+  const float gmin0 = h->eg_min[0], gmin1 = h->eg_min[1], gmin2 = h->eg_min[2];
+  uint32_t chunk_base = 0, chunk_left = 0;  // (lane 0) this wave's piece of the list pool
   for (uint32_t s = gw; s < ns; s += tw) {  // wave-uniform
     const uint32_t c = d.ec_cells[s];
     const int cx = (int)(c % (uint32_t)dx_), cy = (int)((c / (uint32_t)dx_) % (uint32_t)dy_),
@@ -404,139 +399,76 @@ __global__ __launch_bounds__(256) void k_ec_build(PftParams prm, PftDev d) {
 #ifdef PFT_EC_TIMING
     unsigned long long tick_ = wall_clock64();
 #endif
-    const float mx = h->eg_min[0] + ((float)cx + 0.5f) * g, my = h->eg_min[1] + ((float)cy + 0.5f) * g,
-                mz = h->eg_min[2] + ((float)cz + 0.5f) * g;
-    // ---- D: shells of rows around the cell, lanes over rows.  The first three shells one by one (most cells with a
-    // list find their nearest point there); what is left of the cube that holds everything within gate + r of the
-    // centre is then searched in one sweep -- a chain of seven dependent shells was most of this kernel's time ----
-    float best = INFINITY;
-    bool none = false, found = false;
-    // squared distance from the centre to the points [s0, s1) of the cell-sorted cloud, four loads in flight
-    auto scan_points = [&](uint32_t s0, uint32_t s1) {
-      for (uint32_t pos = s0; pos < s1; pos += 4u) {
-        const float4 p0 = d.leaf_pts[pos], p1 = d.leaf_pts[min(pos + 1u, s1 - 1u)], p2 = d.leaf_pts[min(pos + 2u, s1 - 1u)],
-                     p3 = d.leaf_pts[min(pos + 3u, s1 - 1u)];
-        const float a0 = (p0.x - mx) * (p0.x - mx) + ((p0.y - my) * (p0.y - my) + (p0.z - mz) * (p0.z - mz));
-        const float a1 = (p1.x - mx) * (p1.x - mx) + ((p1.y - my) * (p1.y - my) + (p1.z - mz) * (p1.z - mz));
-        const float a2 = (p2.x - mx) * (p2.x - mx) + ((p2.y - my) * (p2.y - my) + (p2.z - mz) * (p2.z - mz));
-        const float a3 = (p3.x - mx) * (p3.x - mx) + ((p3.y - my) * (p3.y - my) + (p3.z - mz) * (p3.z - mz));
-        best = fminf(best, fminf(fminf(a0, a1), fminf(a2, a3)));
-      }
+    const float mx = gmin0 + ((float)cx + 0.5f) * g, my = gmin1 + ((float)cy + 0.5f) * g, mz = gmin2 + ((float)cz + 0.5f) * g;
+    // slab e of the neighbourhood of K cells: z = cz - K + e, y within ky(e) cells of cy, every x
+    auto slab = [&](int z, int ky, uint32_t& a, uint32_t& bnd) {
+      if (z < 0 || z >= dz_) return;
+      const int y0 = max(cy - ky, 0), y1 = min(cy + ky, dy_ - 1);
+      if (y0 > y1) return;
+      a = d.eg_start[(uint32_t)((z * dy_ + y0) * dx_)];
+      bnd = d.eg_start[(uint32_t)((z * dy_ + y1) * dx_ + dx_)];
     };
-    const int KA = min(2, Kmax);
-    for (int k = 0; k <= KA; k++) {
-      const int side = 2 * k + 1;
-      for (int t = lane; t < side * side; t += WAVE) {
-        const int oz = t / side - k, oy = t % side - k;
-        const int z = cz + oz, y = cy + oy;
-        if (z < 0 || z >= dz_ || y < 0 || y >= dy_ || !eg_row_occupied(d, z, y, dy_)) continue;
-        const uint32_t row = (uint32_t)((z * dy_ + y) * dx_);
-        const bool face = abs(oz) == k || abs(oy) == k;
-        for (int sg = 0; sg < (face ? 1 : 2); sg++) {
-          int x0, x1;
-          if (face) {
-            x0 = max(cx - k, 0);
-            x1 = min(cx + k, dx_ - 1);
-          } else {
-            x0 = x1 = sg == 0 ? cx - k : cx + k;
-            if (x0 < 0 || x0 >= dx_) continue;
-          }
-          if (x0 > x1) continue;
-          scan_points(d.eg_start[row + (uint32_t)x0], d.eg_start[row + (uint32_t)x1 + 1u]);
-        }
-      }
-      const float wb = wave_min(best);
-      const float reach = (float)k * g + hh;  // every point not seen yet is at least this far from the centre
-      if (wb <= reach * reach * 0.999f) {
-        found = true;
-        break;
-      }
-      if (reach - r > gate) {  // no query of this cell has a neighbour inside the gate
-        none = true;
-        break;
-      }
-    }
-    EC_TICK(0);
-    // what is left of the cube of Kmax cells in two sweeps (up to 4 cells, then the rest): a sweep visits every point of
-    // its cube shell, and the whole visible surface of the object lies inside the last one
-    for (int kin = KA, kout = min(4, Kmax); !found && !none && kin < Kmax; kin = kout, kout = Kmax) {
-      const int side = 2 * kout + 1;
+    // ---- D: cubes of 2, 4 and Kmax cells around the cell until the nearest point is inside the cube's reach ----
+    float best = INFINITY;
+    bool found = false;
+    for (int K = min(2, Kmax);; K = K < 4 ? min(4, Kmax) : Kmax) {
       wave_segments_points(
-          segs[w], 2 * side * side,
-          [&](int e, uint32_t& a, uint32_t& bnd) {  // two segments per row: left and right of the part seen before
-            const int t = e >> 1, sg = e & 1;
-            const int oz = t / side - kout, oy = t % side - kout;
-            const int z = cz + oz, y = cy + oy;
-            if (z < 0 || z >= dz_ || y < 0 || y >= dy_ || !eg_row_occupied(d, z, y, dy_)) return;
-            const bool inner = abs(oz) <= kin && abs(oy) <= kin;  // the middle of this row was seen before
-            int x0 = cx - kout, x1 = cx + kout;
-            if (inner) {
-              if (sg == 0)
-                x1 = cx - kin - 1;
-              else
-                x0 = cx + kin + 1;
-            } else if (sg == 1) {
-              return;
+          segs[w], 2 * K + 1, [&](int e, uint32_t& a, uint32_t& bnd) { slab(cz - K + e, K, a, bnd); },
+          [&](const bool* live, const uint32_t* pos) {
+            float4 p[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) p[u] = d.leaf_pts[live[u] ? pos[u] : 0u];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const float dd = (p[u].x - mx) * (p[u].x - mx) + ((p[u].y - my) * (p[u].y - my) + (p[u].z - mz) * (p[u].z - mz));
+              best = live[u] ? fminf(best, dd) : best;
             }
-            x0 = max(x0, 0);
-            x1 = min(x1, dx_ - 1);
-            if (x0 > x1) return;
-            const uint32_t row = (uint32_t)((z * dy_ + y) * dx_);
-            a = d.eg_start[row + (uint32_t)x0];
-            bnd = d.eg_start[row + (uint32_t)x1 + 1u];
-          },
-          [&](bool live, uint32_t pos) {
-            if (!live) return;
-            const float4 p = d.leaf_pts[pos];
-            best = fminf(best, (p.x - mx) * (p.x - mx) + ((p.y - my) * (p.y - my) + (p.z - mz) * (p.z - mz)));
           });
       const float wb = wave_min(best);
-      const float reach = (float)kout * g + hh;  // every point not seen yet is at least this far from the centre
-      if (wb <= reach * reach * 0.999f) found = true;
-      // (after the last sweep everything within Kmax * g + hh >= gate + r of the centre has been seen)
+      const float reach = (float)K * g + hh;  // every point outside the cube is at least this far from the centre
+      found = wb <= reach * reach * 0.999f;
+      if (found || K >= Kmax) break;  // (Kmax * g + hh >= gate + r: nothing farther matters)
     }
-    EC_TICK(1);
+    EC_TICK(0);
     const float D = sqrtf(wave_min(best));
-    if (none || !(D - r <= gate)) {
+    if (!found || !(D - r <= gate)) {  // no query of this cell has a neighbour inside the gate
       if (lane == 0) d.ec_count[s] = 0u;
       EC_TICK(4);
       continue;
     }
     const float T = fminf(D + 2.0f * r, gate + r) + 1.0e-4f, T2 = T * T;
-    // ---- the list: rows within T of the centre, lanes over rows.  One walk: the candidates are staged in LDS (and
+    // ---- the list: the slabs within T of the centre, each trimmed in y.  One walk: the candidates are staged in LDS (and
     // counted), then allotted in the pool and copied out; a list longer than the staging area is walked a second time ----
-    const int KT = (int)ceilf((T + hh) * inv_g), side = 2 * KT + 1;
+    const int KT = (int)ceilf((T + hh) * inv_g);
     uint32_t total = 0, base = 0;
     if (lane == 0) wcnt[w] = 0u;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (int pass = 0; pass < 2; pass++) {
       wave_segments_points(
-          segs[w], side * side,
-          [&](int t, uint32_t& a, uint32_t& bnd) {
-            const int oz = t / side - KT, oy = t % side - KT;
-            const int z = cz + oz, y = cy + oy;
-            if (z < 0 || z >= dz_ || y < 0 || y >= dy_ || !eg_row_occupied(d, z, y, dy_)) return;
-            const float lz = fmaxf((float)abs(oz) * g - hh, 0.0f) * 0.9999f, ly = fmaxf((float)abs(oy) * g - hh, 0.0f) * 0.9999f;
-            const float lyz = ly * ly + lz * lz;
-            if (lyz > T2) return;
-            const int kx = (int)floorf((sqrtf(T2 - lyz) + hh) * inv_g) + 1;
-            const int x0 = max(cx - kx, 0), x1 = min(cx + kx, dx_ - 1);
-            const uint32_t row = (uint32_t)((z * dy_ + y) * dx_);
-            a = d.eg_start[row + (uint32_t)x0];
-            bnd = d.eg_start[row + (uint32_t)x1 + 1u];
+          segs[w], 2 * KT + 1,
+          [&](int e, uint32_t& a, uint32_t& bnd) {
+            const int oz = e - KT;
+            const float lz = fmaxf((float)abs(oz) * g - hh, 0.0f) * 0.9999f;  // the slab is at least this far away in z
+            if (lz * lz > T2) return;
+            slab(cz + oz, (int)floorf((sqrtf(T2 - lz * lz) + hh) * inv_g) + 1, a, bnd);
           },
-          [&](bool live, uint32_t pos) {
-            if (!live) return;
-            const float4 p = d.leaf_pts[pos];
-            const float ex = p.x - mx, ey = p.y - my, ez = p.z - mz;
-            if (ex * ex + (ey * ey + ez * ez) <= T2) {
-              const uint32_t k = atomicAdd(&wcnt[w], 1u);
-              const float4 e = make_float4(p.x, p.y, p.z, __uint_as_float(pos));
-              if (pass == 1)
-                d.ec_list[base + k] = e;
-              else if (k < EC_STAGE)
-                stage[w][k] = e;
+          [&](const bool* live, const uint32_t* pos) {
+            float4 pp[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) pp[u] = d.leaf_pts[live[u] ? pos[u] : 0u];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const float4 p = pp[u];
+              const float ex = p.x - mx, ey = p.y - my, ez = p.z - mz;
+              if (live[u] && ex * ex + (ey * ey + ez * ez) <= T2) {
+                const uint32_t k = atomicAdd(&wcnt[w], 1u);
+                const float4 e = make_float4(p.x, p.y, p.z, __uint_as_float(pos[u]));
+                if (pass == 1)
+                  d.ec_list[base + k] = e;
+                else if (k < EC_STAGE)
+                  stage[w][k] = e;
+              }
             }
           });
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -545,7 +477,23 @@ __global__ __launch_bounds__(256) void k_ec_build(PftParams prm, PftDev d) {
       if (pass == 0) {
         total = wcnt[w];
         if (lane == 0) {
-          base = atomicAdd(&d.hdr->ec_pool_used, total);
+          // the pool is handed out in chunks: one returning atomic per list on the header's counter -- 22 000 of them on
+          // one cache line, which every wave also reads -- was four fifths of this kernel's time (540 against 120 us)
+          if (total > chunk_left) {
+            if (total > EC_CHUNK / 2u) {
+              base = atomicAdd(&d.hdr->ec_pool_used, total);  // a long list: its own piece, the chunk stays
+            } else {
+              chunk_base = atomicAdd(&d.hdr->ec_pool_used, EC_CHUNK);
+              chunk_left = EC_CHUNK;
+              base = chunk_base;
+              chunk_base += total;
+              chunk_left -= total;
+            }
+          } else {
+            base = chunk_base;
+            chunk_base += total;
+            chunk_left -= total;
+          }
           wcnt[w] = 0u;
         }
         base = (uint32_t)__shfl((int)base, 0);
@@ -700,7 +648,7 @@ __global__ __launch_bounds__(256) void k_likelihood_exact(PftParams prm, PftDev 
   const uint32_t wgs_before = grp * gq + min(grp, gr);
   const uint32_t it_begin = (uint32_t)((unsigned long long)n_items * wgs_before / gridDim.x);
   const uint32_t it_end = (uint32_t)((unsigned long long)n_items * (wgs_before + wgs_in_grp) / gridDim.x);
-  uint32_t* ctr = &d.hdr->lik_ctr[grp * 16u];
+  uint32_t* ctr = &d.hdr->lik_ctr[grp * PFT_LIK_CTR_STRIDE];
   for (uint32_t item_v = it_begin + (blockIdx.x / G) * (uint32_t)nw + wave_id(); item_v < it_end;) {
     const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item_v);
     const uint32_t pi = item / nchunk, ch = item % nchunk;

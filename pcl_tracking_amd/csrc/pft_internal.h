@@ -26,7 +26,12 @@
 #define PFT_JUMP_MAX_LEVEL 4     // 2^12 cells x u16 = 8 KiB of LDS in the likelihood kernel
 #define PFT_REF_CHUNK 256        // reference points per likelihood work item (upper limit; PftParams::ref_chunk)
 #define PFT_BUILD_THREADS 1024
+#ifndef PFT_LIK_GROUPS
 #define PFT_LIK_GROUPS 64        // likelihood kernel: groups of workgroups that share a dynamic work-item counter
+#endif
+#ifndef PFT_LIK_CTR_STRIDE
+#define PFT_LIK_CTR_STRIDE 16u    // uint32 between two groups' counters
+#endif
 #ifndef PFT_LIK_THREADS
 #define PFT_LIK_THREADS 1024   // likelihood workgroup size
 #endif
@@ -99,9 +104,6 @@ struct PftHeader {  // lives in HBM; written by kernels, read by later kernels (
   float eg_g, eg_inv_g, eg_min[3];
   int32_t eg_dim[3];
   uint32_t eg_ncells;
-  uint32_t ec_nslots;           // exact-NN mode: grid cells hit by at least one query this iteration (candidate lists)
-  uint32_t ec_pool_used;        // exact-NN mode: candidate entries allotted so far
-  unsigned long long eq_totals;  // exact-NN mode: (64-query blocks << 32) | queries of the cells allotted so far (k_ec_slots)
   uint32_t p_active;            // KLD variant: current particle_num_ (written by init / k_resample_kld)
   uint32_t kld_k;               // KLD variant: distinct bins of the last resample (diagnostic)
   unsigned long long stat_queries, stat_scanned;
@@ -109,8 +111,13 @@ struct PftHeader {  // lives in HBM; written by kernels, read by later kernels (
   unsigned long long ticks[32];  // wall_clock64() (100 MHz) at phase boundaries: [0..15] octree, [16..31] population
   // likelihood kernel: per group of workgroups, the next work item of the group's range (one counter per 64-byte line;
   // reset by the crop kernel of the same iteration)
-  uint32_t lik_ctr[PFT_LIK_GROUPS * 16];
-  uint32_t crop_ticket;  // one-pass crop: workgroups take their logical index here (the last one resets it)
+  alignas(128) uint32_t lik_ctr[PFT_LIK_GROUPS * PFT_LIK_CTR_STRIDE];
+  // exact-NN mode: running totals taken with returning atomics by every wave of k_ec_slots / k_ec_build.  In a cache line
+  // of their own: next to the grid geometry, which the same waves READ, 22 000 atomics cost 540 us (25 ns each)
+  alignas(128) uint32_t ec_nslots;  // grid cells hit by at least one query this iteration (candidate lists)
+  uint32_t ec_pool_used;            // candidate entries allotted so far
+  unsigned long long eq_totals;     // (64-query blocks << 32) | queries of the cells allotted so far (k_ec_slots)
+  alignas(128) uint32_t crop_ticket;  // one-pass crop: workgroups take their logical index here (the last one resets it)
   uint32_t pop_bar[4];   // population kernel: arrival counters of its three device-scope barriers + "done" (self-resetting)
 };
 
@@ -151,7 +158,6 @@ struct PftDev {  // device pointers (host-side struct, passed by value)
   uint32_t* eg_cnt;          // exact-NN mode: [eg_cap] cell counts / fill cursors
   uint32_t* eg_tile;         // exact-NN mode: per-2048-cell tile sums
   uint32_t eg_cap;           // exact-NN mode: cells available
-  uint32_t* eg_rowocc;       // exact-NN mode: [eg_cap / 32 + 1] bit (z * dim_y + y) = the grid row holds a point
   uint32_t* ec_slot;         // exact-NN mode: [eg_cap] 0 = no query in this cell, 1 = hit (before the slots are allotted), 0xffffffff = no list, else list slot + 2
   uint32_t* ec_cells;        // exact-NN mode: [PFT_EC_SLOTS] cell of every list slot
   uint32_t* ec_count;        // exact-NN mode: [PFT_EC_SLOTS] candidates of the list (0xffffffff: the pool was full, no list)

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(1024) void k_crop_scatter(const float4* __restrict_
     out[s_base + pos] = make_float4(p.x, p.y, p.z, __uint_as_float(k));
     out_idx[s_base + pos] = (int32_t)i;
   }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x < PFT_LIK_GROUPS) hdr->lik_ctr[threadIdx.x * 16u] = 0u;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x < PFT_LIK_GROUPS) hdr->lik_ctr[threadIdx.x * PFT_LIK_CTR_STRIDE] = 0u;
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
     hdr->n_crop = s_base + total;
     if (host_stat) host_stat[0] = s_base + total;
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(1024) void k_crop_onepass(const float4* __restrict_
     out[s_base + pos] = make_float4(p.x, p.y, p.z, __uint_as_float(kk));
     out_idx[s_base + pos] = (int32_t)i;
   }
-  if (b == nb - 1 && threadIdx.x < PFT_LIK_GROUPS) hdr->lik_ctr[threadIdx.x * 16u] = 0u;
+  if (b == nb - 1 && threadIdx.x < PFT_LIK_GROUPS) hdr->lik_ctr[threadIdx.x * PFT_LIK_CTR_STRIDE] = 0u;
   if (b == nb - 1 && threadIdx.x == 0) {
     atomicExch(&hdr->crop_ticket, 0u);  // every workgroup of this launch has taken its ticket by now
     hdr->n_crop = s_base + total;

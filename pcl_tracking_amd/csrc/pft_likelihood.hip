@@ -105,7 +105,7 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
   const uint32_t small_len = prm.split_last ? prm.ref_chunk / prm.split_last : 0u;
   const uint32_t it_begin = 0u, it_end = np_grp * nchunk, big_items = np_grp * nbig;
   const uint32_t lw = (blockIdx.x / G) * (uint32_t)nw + (uint32_t)w;
-  uint32_t* ctr = &d.hdr->lik_ctr[grp * 16u];
+  uint32_t* ctr = &d.hdr->lik_ctr[grp * PFT_LIK_CTR_STRIDE];
   const double res = prm.res;
   const double maxd2 = prm.maxd2;
   const double wd = prm.dist_w, whsv = prm.hsv_w;
@@ -159,7 +159,7 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         const float flx = floorf(tx), fly = floorf(ty), flz = floorf(tz);
         // inside the box on all three axes: smallest coordinate >= 0 and largest < 2^D (two three-operand instructions and
         // two compares instead of six compares)
-        const bool inside = (fminf(fminf(tx, ty), tz) >= 0.0f) & (fmaxf(fmaxf(tx, ty), tz) < cx.ncell);
+        const bool inside = (int)(fminf(fminf(tx, ty), tz) >= 0.0f) & (int)(fmaxf(fmaxf(tx, ty), tz) < cx.ncell);
         const float fx = tx - flx, fy = ty - fly, fz = tz - flz;
         const float mg = cx.margin, mh = 1.0f - cx.margin;
         const uint32_t kx = inside ? (uint32_t)flx : 0u, ky = inside ? (uint32_t)fly : 0u,
@@ -381,7 +381,8 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
     }
     val = wave_sum_lane63(val);  // (DPP: 18 instructions against 42 for the shuffle butterfly; the total lands in lane 63)
     if (lane == 63) d.partial[(size_t)pi * nchunk + ch] = val;
-    {
+    {  // (drawing the next item at the START of this one, to hide the atomic's latency, was measured: 188 against 183 us --
+       // the launch then ends with waves still holding an item they drew long ago)
       uint32_t nx = 0;
       if (lane == 0) nx = it_begin + waves_in_grp + atomicAdd(ctr, 1u);
       item_v = (uint32_t)__shfl((int)nx, 0);
