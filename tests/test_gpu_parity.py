@@ -635,6 +635,45 @@ def test_exact_nearest_sorted_and_per_query_paths_agree_bit_for_bit(gpu, data, m
     assert out[0][0]["weight"].max() > 1.2 / 1024
 
 
+def test_exact_nearest_wide_particle_cloud_and_tiny_sizes(gpu, orc, data):
+    """(a) particles spread over half a metre: a tile of 32 particles then touches far more grid cells than the 8 192 entries
+    of the workgroup's LDS count table -- the cells that find their probe window full are counted and placed with global
+    atomics -- and most queries have no neighbour inside the gate; (b) one particle, one to three reference points"""
+    def pair(model, P):
+        o = orc.Tracker(orc.default_config(particle_num=P, threads=0, emulate_pcl_alloc=0, exact_nearest=1, max_distance=0.1))
+        g = gpu.ParticleFilterTracker(seed=1)
+        g.setParticleNum(P)
+        coh = gpu.NearestPairPointCloudCoherence()
+        coh.addPointCoherence(gpu.DistanceCoherence())
+        hc = gpu.HSVColorCoherence()
+        hc.setWeight(0.1)
+        coh.addPointCoherence(hc)
+        coh.setMaximumDistance(0.1)
+        g.setCloudCoherence(coh)
+        for ref, tr, inp in ((g.setReferenceCloud, g.setTrans, g.setInputCloud), (o.set_reference, o.set_trans, o.set_input)):
+            ref(model)
+            tr(scene.initial_trans())
+            inp(data["scene"])
+        return g, o
+
+    def check(g, o, p):
+        G = g.evalWeights(p, want_nn=True)
+        O = o.eval_weights(p, want_nn=True, mats=g.debugPoseToMatrix(p))
+        gate = O["nn_d2"].astype(np.float64) < 0.01
+        np.testing.assert_array_equal(G["nn_idx"][gate], O["nn_idx"][gate])
+        np.testing.assert_array_equal(G["nn_d2"][gate], O["nn_d2"][gate])
+        assert (G["nn_idx"][~gate] == -1).all()
+        assert ulp_diff(G["raw"], O["raw"]).max() <= 1
+        return gate
+
+    g, o = pair(data["model"], 96)
+    gate = check(g, o, particles_around(data["gt"], 96, 77, sig_t=0.25, sig_r=0.8))
+    assert 0.02 < gate.mean() < 0.9
+    for M in (1, 2, 3):
+        g, o = pair(data["model"][:M], 1)
+        check(g, o, particles_around(data["gt"], 1, 5, sig_t=0.0, sig_r=0.0))
+
+
 def test_exact_nearest_edge_cases(gpu, orc, data):
     """empty crop (no input point inside the particles' box) and a gate wider than the crop box"""
     def pair(maxd, cloud, P=8):
