@@ -75,10 +75,10 @@ struct pft_tracker {
   float4* d_ec_list = nullptr;
   // exact-NN mode, cell-sorted queries (sized by the largest particle count x reference size evaluated so far)
   uint32_t *d_eq_cellq = nullptr, *d_eq_nq = nullptr, *d_eq_qbase = nullptr, *d_eq_bbase = nullptr, *d_eq_fill = nullptr,
-           *d_eq_blk = nullptr;
+           *d_eq_blk = nullptr, *d_eq_tiles = nullptr;
   float4* d_eq_sorted = nullptr;
   double* d_eq_out = nullptr;
-  uint32_t eq_cap = 0, eq_blk_cap = 0;
+  uint32_t eq_cap = 0, eq_blk_cap = 0, eq_tiles_cap = 0;
   uint32_t* d_kld_table = nullptr;
   int32_t* d_kld_bins = nullptr;
   uint32_t dbg_builds = 0;
@@ -363,6 +363,8 @@ static void sync_dev(pft_tracker* t) {
   d.eq_out = t->d_eq_out;
   d.eq_cap = t->eq_cap;
   d.eq_blk_cap = t->eq_blk_cap;
+  d.eq_tiles = t->d_eq_tiles;
+  d.eq_tiles_cap = t->eq_tiles_cap;
   d.kld_table = t->d_kld_table;
   d.kld_bins = t->d_kld_bins;
   d.alias_pos = t->d_alias_pos;
@@ -587,7 +589,7 @@ extern "C" void pft_destroy(pft_tracker* t) {
   dfree(t->d_pt_key64); dfree(t->sort.keys[0]); dfree(t->sort.keys[1]); dfree(t->sort.vals[0]); dfree(t->sort.vals[1]);
   dfree(t->sort.hist); dfree(t->sort.tile_cnt); dfree(t->sort.tile_box); if (t->h_stat) hipHostFree(t->h_stat);
   dfree(t->d_partial); dfree(t->d_alias_list); dfree(t->d_alias_pos); dfree(t->d_raw_w);
-  dfree(t->d_alias_pref); dfree(t->d_pop_part); dfree(t->d_kld_table); dfree(t->d_kld_bins); dfree(t->d_eg_start); dfree(t->d_eg_cnt); dfree(t->d_eg_tile); dfree(t->d_ec_slot); dfree(t->d_ec_cells); dfree(t->d_ec_count); dfree(t->d_ec_base); dfree(t->d_ec_list); dfree(t->d_eq_cellq); dfree(t->d_eq_nq); dfree(t->d_eq_qbase); dfree(t->d_eq_bbase); dfree(t->d_eq_fill); dfree(t->d_eq_blk); dfree(t->d_eq_sorted); dfree(t->d_eq_out); dfree(t->d_hdr); dfree(t->d_nn_idx); dfree(t->d_nn_d2); dfree(t->d_dbg_part);
+  dfree(t->d_alias_pref); dfree(t->d_pop_part); dfree(t->d_kld_table); dfree(t->d_kld_bins); dfree(t->d_eg_start); dfree(t->d_eg_cnt); dfree(t->d_eg_tile); dfree(t->d_ec_slot); dfree(t->d_ec_cells); dfree(t->d_ec_count); dfree(t->d_ec_base); dfree(t->d_ec_list); dfree(t->d_eq_cellq); dfree(t->d_eq_nq); dfree(t->d_eq_qbase); dfree(t->d_eq_bbase); dfree(t->d_eq_fill); dfree(t->d_eq_blk); dfree(t->d_eq_tiles); dfree(t->d_eq_sorted); dfree(t->d_eq_out); dfree(t->d_hdr); dfree(t->d_nn_idx); dfree(t->d_nn_d2); dfree(t->d_dbg_part);
   dfree(t->d_dbg_hdr); dfree(t->d_dbg_f);
   dfree(t->sv_part); dfree(t->sv_alias_list); dfree(t->sv_alias_pref); dfree(t->sv_alias_pos); dfree(t->sv_hdr);
   if (t->own_stream && t->stream) hipStreamDestroy(t->stream);
@@ -781,18 +783,23 @@ static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32
       // beyond that, or if the allocation fails, the per-query kernel serves)
       const unsigned long long nq = (unsigned long long)np * t->prm.M;
       if (nq > t->eq_cap && nq <= (1ull << 30)) {
-        dfree(t->d_eq_sorted); dfree(t->d_eq_out); dfree(t->d_eq_blk);
-        t->d_eq_sorted = nullptr; t->d_eq_out = nullptr; t->d_eq_blk = nullptr;
-        t->eq_cap = t->eq_blk_cap = 0;
+        dfree(t->d_eq_sorted); dfree(t->d_eq_out); dfree(t->d_eq_blk); dfree(t->d_eq_tiles);
+        t->eq_cap = t->eq_blk_cap = t->eq_tiles_cap = 0;
         const size_t nblk = (size_t)(nq / 64u) + PFT_EC_SLOTS + 64u;
+        size_t ppw = ((size_t)np + (size_t)t->num_cus - 1u) / (size_t)t->num_cus;  // as pftk_likelihood_exact tiles the particles
+        ppw = ppw < 1u ? 1u : (ppw > 32u ? 32u : ppw);
+        const size_t ntiles = ((size_t)np + ppw - 1u) / ppw + 1u;
         if (dalloc(&t->d_eq_sorted, (size_t)nq) == hipSuccess && dalloc(&t->d_eq_out, (size_t)nq) == hipSuccess &&
             dalloc(&t->d_eq_blk, nblk) == hipSuccess) {
           t->eq_cap = (uint32_t)nq;
           t->eq_blk_cap = (uint32_t)nblk;
+          // the per-tile count tables are optional (k_eq_scatter counts its tile again without them)
+          const size_t want = ntiles < 4096u ? ntiles : 4096u;
+          if (dalloc(&t->d_eq_tiles, want * 2u * 8192u) == hipSuccess) t->eq_tiles_cap = (uint32_t)want;
+          else (void)hipGetLastError();
         } else {
           (void)hipGetLastError();
           dfree(t->d_eq_sorted); dfree(t->d_eq_out); dfree(t->d_eq_blk);
-          t->d_eq_sorted = nullptr; t->d_eq_out = nullptr; t->d_eq_blk = nullptr;
         }
       }
       dq.eq_sorted = t->d_eq_sorted;
@@ -800,6 +807,8 @@ static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32
       dq.eq_blk = t->d_eq_blk;
       dq.eq_cap = t->eq_cap;
       dq.eq_blk_cap = t->eq_blk_cap;
+      dq.eq_tiles = t->d_eq_tiles;
+      dq.eq_tiles_cap = t->eq_tiles_cap;
     }
     {
       ProfScope ps(t, PFT_K_OCTREE);

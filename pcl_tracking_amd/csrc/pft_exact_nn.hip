@@ -256,6 +256,11 @@ __global__ __launch_bounds__(1024) void k_ec_mark(PftParams prm, PftDev d, uint3
   __syncthreads();
   for (uint32_t e = threadIdx.x; e < EQ_TAB; e += blockDim.x)
     if (key[e] != EQ_EMPTY && val[e]) atomicAdd(&d.eq_cellq[key[e]], val[e]);
+  // the table is kept for k_eq_scatter, which would otherwise count the same tile again
+  if (d.eq_tiles && blockIdx.x < d.eq_tiles_cap) {
+    uint32_t* out = d.eq_tiles + (size_t)blockIdx.x * 2u * EQ_TAB;
+    for (uint32_t e = threadIdx.x; e < 2u * EQ_TAB; e += blockDim.x) out[e] = eq_lds[e];
+  }
 }
 
 // the cells with queries get list slots (order irrelevant) -- and, for the cell-sorted search, their segment of the
@@ -809,12 +814,17 @@ __global__ __launch_bounds__(1024) void k_eq_scatter(PftParams prm, PftDev d, ui
     return cnt == EC_NOLIST ? EQ_INLINE_SHELL : (cnt == 0u ? EQ_INLINE_EMPTY : 0u);
   };
   if (n_crop > 0) {
-    eq_tile_queries(prm, d, p0, p1, [&](uint32_t, uint32_t, float qx, float qy, float qz) {
-      int cx, cy, cz;
-      if (!eg_query_cell(h, qx, qy, qz, cx, cy, cz)) return;
-      const uint32_t e = eq_insert(key, (uint32_t)((cz * dy_ + cy) * dx_ + cx));
-      if (e < EQ_TAB) atomicAdd(&val[e], 1u);
-    });
+    if (d.eq_tiles && blockIdx.x < d.eq_tiles_cap) {  // the tile's cells and counts as k_ec_mark left them
+      const uint32_t* in = d.eq_tiles + (size_t)blockIdx.x * 2u * EQ_TAB;
+      for (uint32_t e = threadIdx.x; e < 2u * EQ_TAB; e += blockDim.x) eq_lds[e] = in[e];
+    } else {
+      eq_tile_queries(prm, d, p0, p1, [&](uint32_t, uint32_t, float qx, float qy, float qz) {
+        int cx, cy, cz;
+        if (!eg_query_cell(h, qx, qy, qz, cx, cy, cz)) return;
+        const uint32_t e = eq_insert(key, (uint32_t)((cz * dy_ + cy) * dx_ + cx));
+        if (e < EQ_TAB) atomicAdd(&val[e], 1u);
+      });
+    }
     __syncthreads();
     for (uint32_t e = threadIdx.x; e < EQ_TAB; e += blockDim.x) {
       if (key[e] == EQ_EMPTY) continue;

@@ -173,6 +173,8 @@ struct PftDev {  // device pointers (host-side struct, passed by value)
   float4* eq_sorted;         // [eq_cap] {qx, qy, qz, query id = particle * M + reference position}
   double* eq_out;            // [eq_cap] by query id: the point coherence of the pair (0: no neighbour inside the gate)
   uint32_t eq_cap, eq_blk_cap;  // 0: the per-query kernel is used instead
+  uint32_t* eq_tiles;        // [eq_tiles_cap][2 * 8192] per tile of particles: the LDS count table of k_ec_mark (cells, counts)
+  uint32_t eq_tiles_cap;
   uint32_t* kld_table;       // KLD variant: open-addressing table of first occurrences, 2 x pow2(kld_max) entries
   int32_t* kld_bins;         // KLD variant: 6 ints per candidate
   uint32_t* host_stat;  // pinned host memory, device-visible: [0] last n_crop, [1] last octree depth (read by the
