@@ -275,19 +275,21 @@ __global__ __launch_bounds__(256) void k_ec_slots(PftDev d) {
     const bool hit = nq != 0u;
     const unsigned long long m = __ballot(hit);
     if (!m) continue;
-    const uint32_t nb = (nq + 63u) >> 6;
-    const unsigned long long mine = ((unsigned long long)nb << 32) | nq;  // (blocks << 32) | queries
-    const unsigned long long incl = wave_incl_scan(mine);
     const int first = __ffsll((long long)m) - 1;
     uint32_t base = 0;
-    unsigned long long qb = 0;
     if (lane == first) base = atomicAdd(&h->ec_nslots, (uint32_t)__popcll(m));
-    if (lane == WAVE - 1) qb = atomicAdd(&h->eq_totals, incl);
     base = (uint32_t)__shfl((int)base, first);
+    const uint32_t my_slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const bool placed = hit && my_slot < PFT_EC_SLOTS;  // (a cell beyond the slot capacity gets no list and no segment)
+    const uint32_t nb = placed ? (nq + 63u) >> 6 : 0u;
+    const unsigned long long mine = ((unsigned long long)nb << 32) | (placed ? nq : 0u);  // (blocks << 32) | queries
+    const unsigned long long incl = wave_incl_scan(mine);
+    unsigned long long qb = 0;
+    if (lane == WAVE - 1) qb = atomicAdd(&h->eq_totals, incl);
     qb = __shfl(qb, WAVE - 1) + incl - mine;
     if (hit) {
-      const uint32_t sl = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      if (sl < PFT_EC_SLOTS) {
+      const uint32_t sl = my_slot;
+      if (placed) {
         d.ec_cells[sl] = c;
         d.eq_nq[sl] = nq;
         d.eq_qbase[sl] = (uint32_t)qb;
@@ -886,6 +888,7 @@ __global__ __launch_bounds__(256) void k_eq_search(PftParams prm, PftDev d) {
   for (uint32_t bv = gw; bv < nb; bv += tw) {
     const uint32_t blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv);
     const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.eq_blk[blk]);
+    if (slot >= PFT_EC_SLOTS) continue;  // (never written by k_ec_slots)
     const uint32_t j0 = (blk - d.eq_bbase[slot]) * 64u, nq = d.eq_nq[slot];
     const uint32_t n = min(64u, nq - j0);
     const uint32_t cnt = d.ec_count[slot];
