@@ -159,3 +159,69 @@ def test_concurrent_trackers_are_independent():
         for k, t in enumerate(ts):
             together[k].append(t.getResult().tobytes())
     assert together == alone
+
+
+def test_exact_nearest_pair_mode_at_configs1_size():
+    """`NearestPairPointCloudCoherence` at BASELINE configs[1] size (8 192 particles x 2 048 reference points on the 50 000-point
+    cloud), through properties that need no oracle run of 16.8 million exhaustive searches:
+      * the true nearest neighbour is never farther than the approximate search's neighbour of the same query;
+      * a random sample of queries agrees with a numpy exhaustive search over the cropped cloud (index and float distance);
+      * the cell-sorted search (default) and the per-query list walk give the same weights bit for bit."""
+    import os
+
+    from pcl_tracking_amd import tracker as gpu
+
+    P, M = 8192, 2048
+    model, cloud = scene.make_model(M), scene.make_scene(50000)
+    p = particles_around(scene.model_gt_pose(), P, 12)
+
+    def handle(exact):
+        g = gpu.ParticleFilterTracker(seed=1)
+        g.setParticleNum(P)
+        coh = gpu.NearestPairPointCloudCoherence() if exact else gpu.ApproxNearestPairPointCloudCoherence()
+        coh.addPointCoherence(gpu.DistanceCoherence())
+        hc = gpu.HSVColorCoherence()
+        hc.setWeight(0.1)
+        coh.addPointCoherence(hc)
+        coh.setSearchMethod(gpu.OctreeSearch(0.01))
+        coh.setMaximumDistance(0.1)
+        g.setCloudCoherence(coh)
+        g.setReferenceCloud(model)
+        g.setTrans(scene.initial_trans())
+        g.setInputCloud(cloud)
+        return g
+
+    E = handle(True).evalWeights(p, want_nn=True)
+    A = handle(False).evalWeights(p, want_nn=True)
+    np.testing.assert_array_equal(E["crop_idx"], A["crop_idx"])
+    both = (E["nn_idx"] >= 0) & (A["nn_idx"] >= 0) & (A["nn_d2"].astype(np.float64) < 0.01)
+    assert both.mean() > 0.3
+    assert (E["nn_d2"][both] <= A["nn_d2"][both]).all()
+    # inside the gate the approximate neighbour is a candidate of the exact search: exact in gate wherever approx is
+    assert (E["nn_idx"][(A["nn_idx"] >= 0) & (A["nn_d2"].astype(np.float64) < 0.01)] >= 0).all()
+    # exhaustive check of a sample (float arithmetic as pointSquaredDist: dx2 + (dy2 + dz2), ties to the lowest index)
+    mats = handle(True).debugPoseToMatrix(p).reshape(P, 3, 4)
+    crop = cloud[E["crop_idx"]]
+    cx, cy, cz = crop["x"], crop["y"], crop["z"]
+    rng = np.random.default_rng(3)
+    nn_idx, nn_d2 = E["nn_idx"].reshape(P, M), E["nn_d2"].reshape(P, M)
+    for pi, j in zip(rng.integers(0, P, 300), rng.integers(0, M, 300)):
+        T = mats[pi]
+        r = np.array([model["x"][j], model["y"][j], model["z"][j]], np.float32)
+        q = [np.float32(np.float32(np.float32(T[a, 0] * r[0]) + np.float32(T[a, 1] * r[1])) + np.float32(T[a, 2] * r[2])) + T[a, 3]
+             for a in range(3)]
+        q = [np.float32(v) for v in q]
+        dx, dy, dz = cx - q[0], cy - q[1], cz - q[2]
+        d2 = (dx * dx + (dy * dy + dz * dz)).astype(np.float32)
+        k = int(np.argmin(d2))  # (argmin returns the first minimum: the lowest index)
+        if np.float64(d2[k]) < 0.01:
+            assert nn_idx[pi, j] == k, (pi, j)  # (position in the cropped cloud)
+            assert nn_d2[pi, j] == d2[k]
+        else:
+            assert nn_idx[pi, j] == -1
+    os.environ["PFT_EXACT_PER_QUERY"] = "1"
+    try:
+        Q = handle(True).evalWeights(p)
+    finally:
+        del os.environ["PFT_EXACT_PER_QUERY"]
+    np.testing.assert_array_equal(Q["raw"], E["raw"])
