@@ -25,7 +25,9 @@
 #define PFT_MAX_GROW 40
 #define PFT_JUMP_MAX_LEVEL 4     // 2^12 cells x u16 = 8 KiB of LDS in the likelihood kernel
 #define PFT_REF_CHUNK 256        // reference points per likelihood work item (upper limit; PftParams::ref_chunk)
+#ifndef PFT_BUILD_THREADS
 #define PFT_BUILD_THREADS 1024
+#endif
 #ifndef PFT_LIK_GROUPS
 #define PFT_LIK_GROUPS 64        // likelihood kernel: groups of workgroups that share a dynamic work-item counter
 #endif

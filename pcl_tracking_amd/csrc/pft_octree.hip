@@ -405,9 +405,9 @@ __device__ __forceinline__ bool build_tree(const PftParams& prm, const PftDev& d
       if (tid == 0) S.err |= 1u;
     } else {
 #define DN_RANK(l, i) (dn_pref[l][(i) >> 5] + __popc(dn_bits[l][(i) >> 5] & ((1u << ((i) & 31u)) - 1u)))
-      {  // node words of the levels below J: 1 + 8 + 64 + 512 candidates, one thread each
+      for (uint32_t cand = tid; cand < 585u; cand += nt) {  // node words of the levels below J: 1 + 8 + 64 + 512 candidates
         int l = 0;
-        uint32_t i = tid;
+        uint32_t i = cand;
         while (l < J && i >= (1u << (3 * l))) {
           i -= 1u << (3 * l);
           l++;
