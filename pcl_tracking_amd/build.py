@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OUT_DIR = os.path.join(_HERE, "_build")
 LIB = os.path.join(OUT_DIR, "libpft_hip.so")
-SOURCES = ["pft_kernels.hip", "pft_octree.hip", "pft_octree_sorted.hip", "pft_likelihood.hip", "pft_population.hip", "pft_kld.hip", "pft_exact_nn.hip", "pft_api.hip",
+SOURCES = ["pft_kernels.hip", "pft_octree.hip", "pft_octree_sorted.hip", "pft_likelihood.hip", "pft_population.hip", "pft_kld.hip", "pft_exact_nn.hip", "pft_hull.hip", "pft_api.hip",
            "pft_filters.hip"]
 HEADERS = ["pft_internal.h", "pft_device_utils.h", os.path.join("..", "..", "include", "pft.h"),
            os.path.join("..", "..", "include", "pft_filters.h")]

@@ -38,7 +38,8 @@ struct pft_tracker {
 
   // buffers
   pft_point_xyzrgba* d_ref_raw = nullptr;
-  float4 *d_ref_xyz = nullptr, *d_ref_hsv = nullptr;
+  float4 *d_ref_xyz = nullptr, *d_ref_hsv = nullptr, *d_ref_box = nullptr;
+  size_t bbox_part_cap = 0;
   uint32_t ref_cap = 0;
   pft_point_xyzrgba* d_in_raw = nullptr;
   float4* d_in_pts = nullptr;
@@ -315,6 +316,7 @@ static void dfree(T*& p) {
 static void sync_dev(pft_tracker* t) {
   PftDev& d = t->dev;
   d.ref_xyz = t->d_ref_xyz;
+  d.ref_box = t->d_ref_box;
   d.ref_hsv = t->d_ref_hsv;
   d.in_pts = t->d_in_pts;
   d.N = t->N;
@@ -323,6 +325,7 @@ static void sync_dev(pft_tracker* t) {
   d.mats = t->d_mats;
   d.bbox_part = t->d_bbox_part;
   d.bbox_grid = (uint32_t)t->num_cus;
+  d.bbox_part_cap = (uint32_t)t->bbox_part_cap;
   d.bbox6 = t->bound_bbox6 ? static_cast<float*>(t->bound_bbox6) : t->d_bbox6;
   d.crop_counts = t->d_crop_counts;
   d.crop_slots = t->d_crop_slots;
@@ -515,7 +518,8 @@ extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
   A(dalloc(&t->d_part[0], Pt));  // sized P_total so part_all can alias a shard buffer when world_size == 1
   A(dalloc(&t->d_part[1], Pt));
   A(dalloc(&t->d_mats, Pl * 12));
-  A(dalloc(&t->d_bbox_part, (size_t)t->num_cus * 6));
+  t->bbox_part_cap = std::max<size_t>((size_t)t->num_cus, (Pl * 4u + 255u) / 256u);  // (one partial per workgroup of k_aabb / of the fused resample)
+  A(dalloc(&t->d_bbox_part, t->bbox_part_cap * 6));
   A(dalloc(&t->d_bbox6, 8));
   A(dalloc(&t->d_jump, (size_t)1 << (3 * PFT_JUMP_MAX_LEVEL)));
   A(dalloc(&t->d_alias_list, 2 * Pt));
@@ -581,7 +585,7 @@ extern "C" void pft_destroy(pft_tracker* t) {
     hipEventDestroy(p.a);
     hipEventDestroy(p.b);
   }
-  dfree(t->d_ref_raw); dfree(t->d_ref_xyz); dfree(t->d_ref_hsv);
+  dfree(t->d_ref_raw); dfree(t->d_ref_xyz); dfree(t->d_ref_hsv); dfree(t->d_ref_box);
   dfree(t->d_in_raw); dfree(t->d_in_pts);
   dfree(t->d_part[0]); dfree(t->d_part[1]); dfree(t->d_mats); dfree(t->d_bbox_part); dfree(t->d_bbox6);
   dfree(t->d_crop_counts); dfree(t->d_crop_slots); dfree(t->d_crop_pts); dfree(t->d_crop_idx); dfree(t->d_words); dfree(t->d_jump); dfree(t->d_ref_perm);
@@ -610,11 +614,12 @@ extern "C" int pft_set_reference(pft_tracker* t, const pft_point_xyzrgba* pts, s
   hipSetDevice(t->cfg.device_id);
   if (n > t->ref_cap) {
     hipStreamSynchronize(t->stream);
-    dfree(t->d_ref_raw); dfree(t->d_ref_xyz); dfree(t->d_ref_hsv); dfree(t->d_partial); dfree(t->d_ref_perm);
+    dfree(t->d_ref_raw); dfree(t->d_ref_xyz); dfree(t->d_ref_hsv); dfree(t->d_ref_box); dfree(t->d_partial); dfree(t->d_ref_perm);
     HIPCHK(t, dalloc(&t->d_ref_raw, n));
     HIPCHK(t, dalloc(&t->d_ref_perm, n));
     HIPCHK(t, dalloc(&t->d_ref_xyz, n));
     HIPCHK(t, dalloc(&t->d_ref_hsv, n));
+    HIPCHK(t, dalloc(&t->d_ref_box, n));
     t->ref_cap = (uint32_t)n;
   }
   t->prm.M = (uint32_t)n;
@@ -684,7 +689,22 @@ extern "C" int pft_set_reference(pft_tracker* t, const pft_point_xyzrgba* pts, s
     HIPCHK(t, hipMemcpyAsync(t->d_ref_perm, perm.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
     HIPCHK(t, hipMemcpyAsync(t->d_ref_raw, pts, n * sizeof(pft_point_xyzrgba), hipMemcpyHostToDevice, t->stream));
     pftk_pack_reference(t->stream, t->d_ref_raw, (uint32_t)n, t->prm.hsv_argorder, t->d_ref_xyz, t->d_ref_hsv);
+    // A3's input: the points that can be extreme in some rigidly transformed coordinate (the hull's vertices and what lies
+    // within the float evaluation's reach of its facets); PFT_AABB_FULL=1 keeps every point (cross-check, A/B timing)
+    std::vector<uint32_t> keep;
+    if (getenv("PFT_AABB_FULL")) {
+      keep.resize(n);
+      for (size_t i = 0; i < n; i++) keep[i] = (uint32_t)i;
+    } else {
+      pft_aabb_support_subset(pts, n, keep);
+    }
+    std::vector<float4> box(keep.size());
+    for (size_t i = 0; i < keep.size(); i++) box[i] = make_float4(pts[keep[i]].x, pts[keep[i]].y, pts[keep[i]].z, 0.0f);
+    t->prm.M_box = (uint32_t)keep.size();
+    HIPCHK(t, hipMemcpyAsync(t->d_ref_box, box.data(), box.size() * sizeof(float4), hipMemcpyHostToDevice, t->stream));
     HIPCHK(t, hipStreamSynchronize(t->stream));
+  } else {
+    t->prm.M_box = 0;
   }
   t->has_ref = true;
   if (t->h_stat) t->h_stat[0] = t->h_stat[1] = 0;  // new scene: forget the builder hints (unknown depth = all radix passes)
@@ -760,6 +780,32 @@ static void stage_resample(pft_tracker* t) {
 static void stage_aabb(pft_tracker* t, const PftDev& d, uint32_t np, bool finalize) {
   ProfScope ps(t, PFT_K_AABB);
   pftk_aabb(t->stream, t->prm, d, np, finalize);
+}
+// A11 + A1 + A2 + A3 of a steady-state iteration of the fixed-size tracker: ONE launch when the box's support subset is
+// small (pft_hull.hip), the quads that draw the particles fold their boxes; PFT_SPLIT_RESAMPLE=1 keeps the two launches
+// (cross-check -- identical bits --, A/B timing).  The KLD variant, whose resample is a grid-wide loop of its own, and the
+// first iteration after pft_set_particles / init take the separate kernels.
+static void stage_resample_aabb(pft_tracker* t, bool finalize) {
+  static const bool split = getenv("PFT_SPLIT_RESAMPLE") != nullptr || getenv("PFT_RESAMPLE_ONE_LANE") != nullptr;
+  if (!t->prm.kld && t->changed && !split) {
+    sync_dev(t);
+    uint32_t nparts;
+    {
+      ProfScope ps(t, PFT_K_RESAMPLE);
+      nparts = pftk_resample_box(t->stream, t->prm, t->dev, t->resample_epoch, t->d_part[1 - t->cur]);
+    }
+    if (nparts) {
+      t->resample_epoch++;
+      t->cur = 1 - t->cur;
+      sync_dev(t);
+      t->dev.bbox_grid = nparts;  // (the consumers of the partials: the crop kernel, k_bbox_final)
+      if (finalize) pftk_bbox_final(t->stream, t->dev);
+      return;
+    }
+  }
+  if (t->changed) stage_resample(t);
+  sync_dev(t);
+  stage_aabb(t, t->dev, t->prm.kld ? t->Pcap : t->prm.P_local, finalize);
 }
 // A4, A5, A6+A7
 __global__ void k_inject_error(PftHeader* hdr, uint32_t bits) { hdr->error |= bits; }
@@ -876,11 +922,9 @@ extern "C" int pft_compute(pft_tracker* t) {
   const bool graphed = t->use_graph && t->changed && !t->prof && t->graph_frames++ >= 2u &&
                        hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
   for (int it = 0; it < t->cfg.iteration_num; it++) {
-    if (t->changed) stage_resample(t);
-    sync_dev(t);
+    stage_resample_aabb(t, false);
     // KLD variant: launches are sized for the capacity, the kernels take particle_num_ from PftHeader::p_active
     const uint32_t np = t->prm.kld ? t->Pcap : t->prm.P_local;
-    stage_aabb(t, t->dev, np, false);
     stage_crop_octree_likelihood(t, t->dev, np, false, true);
     {
       ProfScope ps(t, PFT_K_POPULATION);
@@ -952,9 +996,7 @@ extern "C" int pft_dist_phase_a(pft_tracker* t, int iteration) {
   int r = check_ready(t);
   if (r != PFT_OK) return r;
   if (!t->initialized) return PFT_ERR_STATE;
-  if (t->changed) stage_resample(t);
-  sync_dev(t);
-  stage_aabb(t, t->dev, t->prm.P_local, true);
+  stage_resample_aabb(t, true);
   return PFT_OK;
 }
 
@@ -1264,6 +1306,8 @@ extern "C" int pft_debug_get_descent_stats(pft_tracker* t, uint64_t* dbg32) {
   int r = read_hdr(t, &h);
   if (r != PFT_OK) return r;
   for (int i = 0; i < 32; i++) dbg32[i] = h.dbg[i];
+  dbg32[30] = t->prm.M_box;  // reference points the box is taken over (pft_hull.hip), of
+  dbg32[31] = t->prm.M;
   if (t->cfg.exact_nearest) {  // the exact-NN mode's bookkeeping of the last iteration (tools/exact_nn_bench.py)
     dbg32[8] = h.ec_nslots;
     dbg32[9] = h.ec_pool_used;

@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/pft.h"
 
 #define PFT_MAX_DEVICES 64      // per-device caches of one-time kernel attributes
@@ -62,6 +64,7 @@ struct PftParams {  // immutable per handle, passed by value to kernels
   uint32_t seed_lo, seed_hi;
   uint32_t P_total, P_local, id_offset;
   uint32_t M, nchunk;
+  uint32_t M_box;      // reference points that can be extreme in a rigidly transformed coordinate (pft_hull.hip): the box's input
   uint32_t ref_chunk;  // reference points per likelihood work item: 64 .. PFT_REF_CHUNK, smaller when there are few particles
   uint32_t split_last;  // s > 0: the last ref_chunk points of the cloud form s items of ref_chunk / s points, handed out last (shorter tail)
   // KLD-adaptive variant (KLDAdaptiveParticleFilterOMPTracker, auto_tracking.cpp:207-222)
@@ -126,6 +129,7 @@ struct PftHeader {  // lives in HBM; written by kernels, read by later kernels (
 struct PftDev {  // device pointers (host-side struct, passed by value)
   const float4* ref_xyz;
   const float4* ref_hsv;
+  const float4* ref_box;    // [M_box] {x, y, z, .} of the box's support subset
   const float4* in_pts;
   uint32_t N;
   pft_particle* part_cur;   // shard being evaluated
@@ -133,6 +137,7 @@ struct PftDev {  // device pointers (host-side struct, passed by value)
   float* mats;
   float* bbox_part;
   uint32_t bbox_grid;
+  uint32_t bbox_part_cap;   // partial boxes bbox_part has room for
   float* bbox6;             // {-xmin,-ymin,-zmin,xmax,ymax,zmax}: max-reducible across ranks
   uint32_t* crop_counts;
   unsigned long long* crop_slots;  // one-pass crop: per workgroup (launch epoch << 32) | kept points, published with atomics
@@ -194,11 +199,14 @@ void pftk_pack_input(hipStream_t s, const pft_point_xyzrgba* d_pts, uint32_t n, 
 void pftk_init_particles(hipStream_t s, const PftParams& p, pft_particle rep, pft_particle* out, float* mats,
                          PftHeader* hdr);
 void pftk_resample(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t epoch, pft_particle* out);
+void pftk_bbox_final(hipStream_t s, const PftDev& d);
+uint32_t pftk_resample_box(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t epoch, pft_particle* out);
 // debug: resample from an explicit (a, q) table instead of the prefix-sum form
 void pftk_resample_table(hipStream_t s, const PftParams& p, const pft_particle* old, const int32_t* a,
                          const double* q, const PftHeader* hdr, uint32_t epoch, pft_particle* out);
 void pftk_pose_to_matrix(hipStream_t s, const pft_particle* p, uint32_t n, float* mats);
 void pftk_aabb(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, bool finalize);
+void pft_aabb_support_subset(const pft_point_xyzrgba* pts, size_t n, std::vector<uint32_t>& keep);  // pft_hull.hip (host)
 // NearestPairPointCloudCoherence mode: uniform grid over the cropped cloud, then the likelihood with the true NN
 void pftk_exact_grid(hipStream_t s, const PftParams& p, const PftDev& d);
 void pftk_likelihood_exact(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, bool debug_nn,

@@ -107,89 +107,6 @@ __global__ void k_resample(PftParams p, const pft_particle* __restrict__ old, Al
   }
 }
 
-// The same resample with FOUR lanes per particle (the product path; k_resample<TABLE> above stays for the explicit-table
-// test hook).  One lane's chain -- two binary searches, Philox, three Box-Muller pairs (log, sqrt, sin, cos in double),
-// six more double sin / cos for the matrix -- is 7 us of pure latency for 8 192 particles; its pieces are independent:
-//   lane 0 of a quad: the alias draw and the gather of the drawn particle
-//   lanes 1..3:       one normal pair each (Philox slot = the lane's role)          -- concurrently with lane 0
-//   then lanes 1..3:  cos / sin of roll / pitch / yaw of the new pose               -- concurrently
-//   lane 0:           the nine matrix products, the stores
-// Every number is formed by the same operations as in the one-lane kernel: bit-identical results.
-__global__ __launch_bounds__(256) void k_resample4(PftParams p, const pft_particle* __restrict__ old, AliasView v,
-                                                   const PftHeader* __restrict__ hdr, uint32_t epoch,
-                                                   pft_particle* __restrict__ out, float* __restrict__ mats) {
-  __shared__ double cD[256], cE[256];
-  v.m = hdr->alias_m;
-  v.nh = hdr->alias_nh;
-  v.sD = (v.m + 255u) / 256u;
-  v.sE = (v.nh + 255u) / 256u;
-  {
-    const uint32_t t = threadIdx.x;
-    if (v.m && t * v.sD < v.m) cD[t] = v.D[min((t + 1u) * v.sD, v.m) - 1u];
-    if (v.nh && t * v.sE < v.nh) cE[t] = v.E[min((t + 1u) * v.sE, v.nh) - 1u];
-  }
-  __syncthreads();
-  v.cD = cD;
-  v.cE = cE;
-  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t li = gt >> 2, role = gt & 3u;
-  const int lane = lane_id(), q0 = lane & ~3;  // first lane of my quad
-  const bool live = li < p.P_local;
-  const uint32_t g = p.id_offset + li;
-  pft_particle s = {0, 0, 0, 1.0f, 0, 0, 0, 0};
-  double z0 = 0.0, z1 = 0.0;
-  if (live) {
-    if (role == 0u) {
-      if (g == 0) {
-        s = hdr->rep;
-      } else {
-        uint32_t o[4];
-        philox4x32(g, 0, epoch, 1, p.seed_lo, p.seed_hi, o);
-        double rU = u53(o[0], o[1]) * (double)p.P_total;
-        const int k = (int)rU;
-        rU -= k;
-        int32_t a_large;
-        const double qk = alias_q(v, (uint32_t)k, old[k].weight, &a_large);
-        int target;
-        if (rU < qk)
-          target = k;
-        else
-          target = (v.pos[k] >> 31) ? a_large : alias_a_small(v, (uint32_t)k);
-        s = old[target];
-      }
-    } else if (g != 0) {
-      normal_pair(p, g, role, epoch, 1, z0, z1);
-    }
-  }
-  // the step noise of ParticleXYZRPY::sample: component += (float)(z * sigma + mean), mean = 0; role r holds the pair of
-  // components 2r - 2, 2r - 1 (x y | z roll | pitch yaw)
-  const float n0 = (role && g != 0) ? (float)(z0 * p.step_sigma[2u * role - 2u] + 0.0) : 0.0f;
-  const float n1 = (role && g != 0) ? (float)(z1 * p.step_sigma[2u * role - 1u] + 0.0) : 0.0f;
-  const float nx = __shfl(n0, q0 + 1), ny = __shfl(n1, q0 + 1), nz = __shfl(n0, q0 + 2), nroll = __shfl(n1, q0 + 2),
-              npitch = __shfl(n0, q0 + 3), nyaw = __shfl(n1, q0 + 3);
-  if (role == 0u && g != 0) {  // (slot 0 of the population is the representative state verbatim: no noise)
-    s.x += nx; s.y += ny; s.z += nz;
-    s.roll += nroll; s.pitch += npitch; s.yaw += nyaw;
-  }
-  // A1: lanes 1..3 take one angle each (double cos / sin rounded to float, as pose_to_matrix)
-  const float roll = __shfl(s.roll, q0), pitch = __shfl(s.pitch, q0), yaw = __shfl(s.yaw, q0);
-  const float ang = role == 1u ? roll : (role == 2u ? pitch : yaw);
-  const float ca = (float)cos((double)ang), sa = (float)sin((double)ang);
-  const float E = __shfl(ca, q0 + 1), F = __shfl(sa, q0 + 1), C = __shfl(ca, q0 + 2), D = __shfl(sa, q0 + 2),
-              A = __shfl(ca, q0 + 3), B = __shfl(sa, q0 + 3);
-  if (live && role == 0u) {
-    out[li] = s;
-    if (mats) {
-      const float DE = D * E, DF = D * F;
-      float m[12];
-      m[0] = A * C;  m[1] = A * DF - B * E;  m[2] = B * F + A * DE;  m[3] = s.x;
-      m[4] = B * C;  m[5] = A * E + B * DF;  m[6] = B * DE - A * F;  m[7] = s.y;
-      m[8] = -D;     m[9] = C * F;           m[10] = C * E;          m[11] = s.z;
-      store_matrix(mats, li, m);
-    }
-  }
-}
-
 __global__ void k_pose_to_matrix(const pft_particle* __restrict__ p, uint32_t n, float* __restrict__ mats) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -299,6 +216,132 @@ __global__ __launch_bounds__(1024) void k_aabb(const float4* __restrict__ ref, u
     aabb_body<true>(ref, reinterpret_cast<const float4*>(smem), M, mats, n_particles, part, s_red);
   else
     aabb_body<false>(ref, nullptr, M, mats, n_particles, part, s_red);
+}
+
+// The same resample with FOUR lanes per particle (the product path; k_resample<TABLE> above stays for the explicit-table
+// test hook).  One lane's chain -- two binary searches, Philox, three Box-Muller pairs (log, sqrt, sin, cos in double),
+// six more double sin / cos for the matrix -- is 7 us of pure latency for 8 192 particles; its pieces are independent:
+//   lane 0 of a quad: the alias draw and the gather of the drawn particle
+//   lanes 1..3:       one normal pair each (Philox slot = the lane's role)          -- concurrently with lane 0
+//   then lanes 1..3:  cos / sin of roll / pitch / yaw of the new pose               -- concurrently
+//   all four:         the nine matrix products; lane 0 stores
+// Every number is formed by the same operations as in the one-lane kernel: bit-identical results.
+// BOX: A2 + A3 in the same launch -- the quad that has drawn a particle also folds the particle's transformed reference
+// cloud into the workgroup's box partial.  Worth it because the box needs only the support subset of the cloud
+// (pft_hull.hip: 84 of the 2 048 points of the bench's model), 21 points per lane; the per-point expression, the
+// translation added after the reduction and the NaN-ignoring min / max are those of k_aabb: the same bits.
+#define PFT_BOX_FUSED_MAX 256u  // support points up to which the box is fused into the resample launch
+template <bool BOX>
+__global__ __launch_bounds__(256) void k_resample4(PftParams p, const pft_particle* __restrict__ old, AliasView v,
+                                                   const PftHeader* __restrict__ hdr, uint32_t epoch,
+                                                   pft_particle* __restrict__ out, float* __restrict__ mats,
+                                                   const float4* __restrict__ box, float* __restrict__ part) {
+  __shared__ double cD[256], cE[256];
+  __shared__ float4 lbox[BOX ? PFT_BOX_FUSED_MAX : 1u];
+  __shared__ float s_red[6][4];
+  if (BOX)
+    for (uint32_t j = threadIdx.x; j < p.M_box; j += blockDim.x) lbox[j] = box[j];
+  v.m = hdr->alias_m;
+  v.nh = hdr->alias_nh;
+  v.sD = (v.m + 255u) / 256u;
+  v.sE = (v.nh + 255u) / 256u;
+  {
+    const uint32_t t = threadIdx.x;
+    if (v.m && t * v.sD < v.m) cD[t] = v.D[min((t + 1u) * v.sD, v.m) - 1u];
+    if (v.nh && t * v.sE < v.nh) cE[t] = v.E[min((t + 1u) * v.sE, v.nh) - 1u];
+  }
+  __syncthreads();
+  v.cD = cD;
+  v.cE = cE;
+  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t li = gt >> 2, role = gt & 3u;
+  const int lane = lane_id(), q0 = lane & ~3;  // first lane of my quad
+  const bool live = li < p.P_local;
+  const uint32_t g = p.id_offset + li;
+  pft_particle s = {0, 0, 0, 1.0f, 0, 0, 0, 0};
+  double z0 = 0.0, z1 = 0.0;
+  if (live) {
+    if (role == 0u) {
+      if (g == 0) {
+        s = hdr->rep;
+      } else {
+        uint32_t o[4];
+        philox4x32(g, 0, epoch, 1, p.seed_lo, p.seed_hi, o);
+        double rU = u53(o[0], o[1]) * (double)p.P_total;
+        const int k = (int)rU;
+        rU -= k;
+        int32_t a_large;
+        const double qk = alias_q(v, (uint32_t)k, old[k].weight, &a_large);
+        int target;
+        if (rU < qk)
+          target = k;
+        else
+          target = (v.pos[k] >> 31) ? a_large : alias_a_small(v, (uint32_t)k);
+        s = old[target];
+      }
+    } else if (g != 0) {
+      normal_pair(p, g, role, epoch, 1, z0, z1);
+    }
+  }
+  // the step noise of ParticleXYZRPY::sample: component += (float)(z * sigma + mean), mean = 0; role r holds the pair of
+  // components 2r - 2, 2r - 1 (x y | z roll | pitch yaw)
+  const float n0 = (role && g != 0) ? (float)(z0 * p.step_sigma[2u * role - 2u] + 0.0) : 0.0f;
+  const float n1 = (role && g != 0) ? (float)(z1 * p.step_sigma[2u * role - 1u] + 0.0) : 0.0f;
+  const float nx = __shfl(n0, q0 + 1), ny = __shfl(n1, q0 + 1), nz = __shfl(n0, q0 + 2), nroll = __shfl(n1, q0 + 2),
+              npitch = __shfl(n0, q0 + 3), nyaw = __shfl(n1, q0 + 3);
+  if (role == 0u && g != 0) {  // (slot 0 of the population is the representative state verbatim: no noise)
+    s.x += nx; s.y += ny; s.z += nz;
+    s.roll += nroll; s.pitch += npitch; s.yaw += nyaw;
+  }
+  // A1: lanes 1..3 take one angle each (double cos / sin rounded to float, as pose_to_matrix)
+  const float roll = __shfl(s.roll, q0), pitch = __shfl(s.pitch, q0), yaw = __shfl(s.yaw, q0);
+  const float ang = role == 1u ? roll : (role == 2u ? pitch : yaw);
+  const float ca = (float)cos((double)ang), sa = (float)sin((double)ang);
+  const float E = __shfl(ca, q0 + 1), F = __shfl(sa, q0 + 1), C = __shfl(ca, q0 + 2), D = __shfl(sa, q0 + 2),
+              A = __shfl(ca, q0 + 3), B = __shfl(sa, q0 + 3);
+  const float DE = D * E, DF = D * F;
+  const float sx = __shfl(s.x, q0), sy = __shfl(s.y, q0), sz = __shfl(s.z, q0);
+  float m[12];  // (every lane of the quad forms the matrix: the box below needs it in all four)
+  m[0] = A * C;  m[1] = A * DF - B * E;  m[2] = B * F + A * DE;  m[3] = sx;
+  m[4] = B * C;  m[5] = A * E + B * DF;  m[6] = B * DE - A * F;  m[7] = sy;
+  m[8] = -D;     m[9] = C * F;           m[10] = C * E;          m[11] = sz;
+  if (live && role == 0u) {
+    out[li] = s;
+    if (mats) store_matrix(mats, li, m);
+  }
+  if (BOX) {
+    float pmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, pmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    if (live) {
+      for (uint32_t j = role; j < p.M_box; j += 4u) {
+        const float4 r = lbox[j];
+        const float x0 = m[0] * r.x + m[1] * r.y + m[2] * r.z, y0 = m[4] * r.x + m[5] * r.y + m[6] * r.z,
+                    z0 = m[8] * r.x + m[9] * r.y + m[10] * r.z;
+        pmn[0] = amin3(pmn[0], x0, x0); pmx[0] = amax3(pmx[0], x0, x0);
+        pmn[1] = amin3(pmn[1], y0, y0); pmx[1] = amax3(pmx[1], y0, y0);
+        pmn[2] = amin3(pmn[2], z0, z0); pmx[2] = amax3(pmx[2], z0, z0);
+      }
+    }
+    const int w = wave_id(), nw = blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      // the translation once per lane that saw a point (monotone: as after the whole reduction), then quad, wave, workgroup
+      float lo = (live && role < p.M_box) ? pmn[k] + m[4 * k + 3] : FLT_MAX;
+      float hi = (live && role < p.M_box) ? pmx[k] + m[4 * k + 3] : -FLT_MAX;
+      lo = wave_min(lo);
+      hi = wave_max(hi);
+      if (lane == 0) {
+        s_red[k][w] = lo;
+        s_red[3 + k][w] = hi;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+      const int k = (int)threadIdx.x;
+      float r = s_red[k][0];
+      for (int i = 1; i < nw; i++) r = k < 3 ? amin3(r, s_red[k][i], s_red[k][i]) : amax3(r, s_red[k][i], s_red[k][i]);
+      part[blockIdx.x * 6 + k] = r;
+    }
+  }
 }
 
 // partials -> b6 = {-xmin,-ymin,-zmin,xmax,ymax,zmax}: one max-reduction (also across ranks) gives the
@@ -572,8 +615,17 @@ void pftk_resample(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t 
                        alias_view(d, p.P_total), (const int32_t*)nullptr, (const double*)nullptr, d.hdr, epoch, out,
                        d.mats);
   else
-    hipLaunchKernelGGL(k_resample4, dim3(cdiv(4u * p.P_local, 256)), dim3(256), 0, s, p, d.part_all,
-                       alias_view(d, p.P_total), d.hdr, epoch, out, d.mats);
+    hipLaunchKernelGGL(k_resample4<false>, dim3(cdiv(4u * p.P_local, 256)), dim3(256), 0, s, p, d.part_all,
+                       alias_view(d, p.P_total), d.hdr, epoch, out, d.mats, (const float4*)nullptr, (float*)nullptr);
+}
+// resample + pose -> matrix + box partials in one launch; returns the number of partials written to d.bbox_part (0: the
+// support subset is too large for the fused form, nothing was launched)
+uint32_t pftk_resample_box(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t epoch, pft_particle* out) {
+  const uint32_t grid = cdiv(4u * p.P_local, 256);
+  if (p.M_box == 0u || p.M_box > PFT_BOX_FUSED_MAX || grid > d.bbox_part_cap) return 0u;
+  hipLaunchKernelGGL(k_resample4<true>, dim3(grid), dim3(256), 0, s, p, d.part_all, alias_view(d, p.P_total), d.hdr, epoch,
+                     out, d.mats, d.ref_box, d.bbox_part);
+  return grid;
 }
 void pftk_resample_table(hipStream_t s, const PftParams& p, const pft_particle* old, const int32_t* a,
                          const double* q, const PftHeader* hdr, uint32_t epoch, pft_particle* out) {
@@ -594,10 +646,13 @@ void pftk_aabb(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_pa
     attr_set[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aabb), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds_max) == hipSuccess;
   uint32_t lds_points = lds_max / 16u;
-  uint32_t lds = p.M <= lds_points ? p.M * 16u : 0u;
-  hipLaunchKernelGGL(k_aabb, dim3(d.bbox_grid), dim3(1024), lds, s, d.ref_xyz, p.M, d.mats, n_particles, d.bbox_part,
+  uint32_t lds = p.M_box <= lds_points ? p.M_box * 16u : 0u;
+  hipLaunchKernelGGL(k_aabb, dim3(d.bbox_grid), dim3(1024), lds, s, d.ref_box, p.M_box, d.mats, n_particles, d.bbox_part,
                      lds_points, d.p_active);
   if (finalize) hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(512), 0, s, d.bbox_part, d.bbox_grid, d.bbox6);
+}
+void pftk_bbox_final(hipStream_t s, const PftDev& d) {
+  hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(512), 0, s, d.bbox_part, d.bbox_grid, d.bbox6);
 }
 void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d, bool from_part, uint32_t epoch,
                const pft_point_xyzrgba* raw) {

@@ -809,3 +809,73 @@ def test_exact_nearest_ties_take_the_lowest_index(gpu, orc, data, kind, path, mo
     np.testing.assert_array_equal(G["nn_idx"][gate], O["nn_idx"][gate])
     np.testing.assert_array_equal(G["nn_d2"][gate], O["nn_d2"][gate])
     assert ulp_diff(G["raw"], O["raw"]).max() <= 1
+
+
+# ---- A3 on the support subset of the reference cloud (pft_hull.hip) ---------------------------------------------
+def _box_points(t):
+    import ctypes as C
+
+    dbg = np.zeros(32, np.uint64)
+    t._check(t._L.pft_debug_get_descent_stats(t._h, dbg.ctypes.data_as(C.c_void_p)))
+    return int(dbg[30]), int(dbg[31])
+
+
+@pytest.mark.parametrize("kind", ["scan", "ball", "noisy_planes", "lattice", "planar", "duplicates", "far_from_origin"])
+def test_bounding_box_over_the_hull_shell_equals_the_box_over_all_points(gpu, data, kind, monkeypatch):
+    """the box of the particles' transformed reference clouds is taken over the reference points that can be extreme in some
+    rigidly transformed coordinate (convex hull + the shell the float evaluation can reach); it must be the box over ALL
+    points bit for bit, for any rotation -- here 4 096 poses with uniformly random orientations and a few exact
+    quarter turns, on clouds that are generic, degenerate (the subset then is the whole cloud) or far from the origin"""
+    rng = np.random.default_rng(abs(hash(kind)) % 1000)
+    n = 2048
+    if kind == "scan":
+        m = data["model"]
+    else:
+        m = np.zeros(n, scene.POINT_DTYPE)
+        m["w"] = 1.0
+        m["rgba"] = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+        if kind == "ball":
+            xyz = rng.normal(0, 1, (n, 3))
+            xyz *= (rng.uniform(0, 1, (n, 1)) ** (1 / 3)) * 0.2 / np.linalg.norm(xyz, axis=1, keepdims=True)
+        elif kind == "noisy_planes":
+            xyz = rng.uniform(-0.2, 0.2, (n, 3))
+            xyz[: n // 2, 2] = 0.1 + rng.normal(0, 1e-4, n // 2)
+            xyz[n // 2:, 0] = -0.15 + rng.normal(0, 1e-6, n - n // 2)
+        elif kind == "lattice":
+            xyz = np.round(rng.uniform(-0.15, 0.15, (n, 3)) / 0.05) * 0.05
+        elif kind == "planar":
+            xyz = rng.uniform(-0.2, 0.2, (n, 3))
+            xyz[:, 1] = 0.03125
+        elif kind == "duplicates":
+            xyz = rng.uniform(-0.2, 0.2, (40, 3))[rng.integers(0, 40, n)]
+        else:
+            xyz = rng.uniform(-0.2, 0.2, (n, 3)) + np.array([31.0, -17.0, 55.0])
+        xyz = xyz.astype(np.float32)
+        m["x"], m["y"], m["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    P = 4096
+    p = np.zeros(P, scene.PARTICLE_DTYPE)
+    p["w"], p["weight"] = 1.0, 1.0 / P
+    for k, name in enumerate(("x", "y", "z")):
+        p[name] = data["gt"][k] + rng.normal(0, 0.3, P)
+    p["roll"], p["yaw"] = rng.uniform(-np.pi, np.pi, P), rng.uniform(-np.pi, np.pi, P)
+    p["pitch"] = np.arcsin(rng.uniform(-1, 1, P))
+    for i, (r, pt, y) in enumerate([(0, 0, 0), (np.pi / 2, 0, 0), (0, np.pi / 2, 0), (0, 0, np.pi / 2), (np.pi, 0, -np.pi / 2)]):
+        p["roll"][i], p["pitch"][i], p["yaw"][i] = r, pt, y
+    out = []
+    for full in (False, True):
+        if full:
+            monkeypatch.setenv("PFT_AABB_FULL", "1")
+        t = gpu.make_reference_tracker(particle_num=P, seed=1)
+        t.setReferenceCloud(m)
+        t.setTrans(scene.initial_trans())
+        t.setInputCloud(data["scene"][:4000])
+        boxes = [t.evalWeights(p[a:a + 512])["bbox"] for a in range(0, P, 512)]  # eight different boxes per cloud
+        out.append((np.stack(boxes), _box_points(t)))
+    (b_sub, (m_sub, m_all)), (b_full, (m_full, _)) = out
+    assert m_full == m_all == n
+    np.testing.assert_array_equal(b_sub, b_full)
+    if kind in ("scan", "ball", "noisy_planes", "far_from_origin"):
+        assert m_sub < n // 2, m_sub  # the subset is what makes the kernel cheap
+    if kind == "planar":
+        assert m_sub == n  # a degenerate cloud keeps every point
+    print(kind, "box over", m_sub, "of", n, "points")
