@@ -29,6 +29,9 @@
 // sequentially (weights in double, poses in float): <= 1 ulp(float) on the sum, ~1e-7 on the pose.
 #include "pft_device_utils.h"
 
+#ifndef PFT_POPC_POLL_SLEEP
+#define PFT_POPC_POLL_SLEEP 1  // s_sleep units (64 cycles) between two polls of a barrier counter
+#endif
 #define STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) d.hdr->ticks[16 + (k)] = wall_clock64(); } while (0)
 
 #define PFT_POPC_THREADS 256
@@ -100,7 +103,7 @@ __device__ __forceinline__ void grid_barrier(PftHeader* hdr, int k, uint32_t G) 
         atomicOr(&hdr->error, 16u);
         break;
       }
-      __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_s_sleep(PFT_POPC_POLL_SLEEP);
     }
     asm volatile("" ::: "memory");
   }
