@@ -879,3 +879,53 @@ def test_bounding_box_over_the_hull_shell_equals_the_box_over_all_points(gpu, da
     if kind == "planar":
         assert m_sub == n  # a degenerate cloud keeps every point
     print(kind, "box over", m_sub, "of", n, "points")
+
+
+def test_bounding_box_hull_shell_random_clouds(gpu, data, monkeypatch):
+    """two dozen random reference clouds of different character and scale (thin shells, clusters with exact duplicates, almost
+    flat slabs, sizes from a millimetre to a hundred metres, off-centre): subset box == full box, bit for bit"""
+    rng = np.random.default_rng(2024)
+    P = 1024
+    for case in range(24):
+        n = int(rng.integers(130, 3000))
+        kind = case % 6
+        if kind == 0:  # thin spherical shell
+            v = rng.normal(0, 1, (n, 3))
+            xyz = v / np.linalg.norm(v, axis=1, keepdims=True) * (1.0 + rng.normal(0, 1e-3, (n, 1)))
+        elif kind == 1:  # clusters with exact duplicates
+            c = rng.uniform(-1, 1, (12, 3))
+            xyz = c[rng.integers(0, 12, n)] + rng.normal(0, 0.05, (n, 3)) * (rng.uniform(0, 1, (n, 1)) > 0.3)
+        elif kind == 2:  # almost flat slab
+            xyz = rng.uniform(-1, 1, (n, 3)) * np.array([1.0, 0.7, 2e-3])
+        elif kind == 3:  # a box surface
+            xyz = rng.uniform(-1, 1, (n, 3))
+            ax = rng.integers(0, 3, n)
+            xyz[np.arange(n), ax] = np.sign(xyz[np.arange(n), ax])
+        elif kind == 4:  # heavy-tailed
+            xyz = rng.standard_t(2.5, (n, 3)) * 0.1
+        else:  # uniform
+            xyz = rng.uniform(-1, 1, (n, 3))
+        scale = 10.0 ** rng.uniform(-3, 2)
+        xyz = xyz * scale + rng.uniform(-1, 1, 3) * scale * rng.choice([0.0, 1.0, 30.0])
+        m = np.zeros(n, scene.POINT_DTYPE)
+        m["w"] = 1.0
+        xyz = xyz.astype(np.float32)
+        m["x"], m["y"], m["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+        p = np.zeros(P, scene.PARTICLE_DTYPE)
+        p["w"], p["weight"] = 1.0, 1.0 / P
+        for k, name in enumerate(("x", "y", "z")):
+            p[name] = rng.normal(0, 1.0, P) * scale
+        p["roll"], p["yaw"] = rng.uniform(-np.pi, np.pi, P), rng.uniform(-np.pi, np.pi, P)
+        p["pitch"] = np.arcsin(rng.uniform(-1, 1, P))
+        boxes = []
+        for full in (False, True):
+            if full:
+                monkeypatch.setenv("PFT_AABB_FULL", "1")
+            else:
+                monkeypatch.delenv("PFT_AABB_FULL", raising=False)
+            t = gpu.make_reference_tracker(particle_num=P, seed=1)
+            t.setReferenceCloud(m)
+            t.setTrans(scene.initial_trans())
+            t.setInputCloud(data["scene"][:1000])
+            boxes.append(np.stack([t.evalWeights(p[a:a + 256])["bbox"] for a in range(0, P, 256)]))
+        np.testing.assert_array_equal(boxes[0], boxes[1], err_msg="case %d kind %d n %d scale %g" % (case, kind, n, scale))
