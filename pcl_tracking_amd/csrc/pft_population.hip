@@ -387,13 +387,20 @@ __global__ void k_alias_materialize(const pft_particle* __restrict__ P, AliasVie
 
 // n = particles (KLD variant: the capacity; the kernel reads the live count).  from_partials != 0: the raw weights are
 // first formed from the likelihood partial sums of d.partial (fuses k_finalize_raw); d.raw_w, if set, receives them.
+#ifndef PFT_POP_WGS
+#define PFT_POP_WGS 128u  // workgroups up to which a thread keeps one particle: at 65 536 particles (the replicated population
+                          // of an 8-GPU run) 128 workgroups with two particles per thread take 60.9 us per frame, 256 with one 68.3, 64
+                          // with four 67.1 (tools/diag/pop_wgs.sh; PFT_POP_MAX_WGS overrides)
+#endif
 void pftk_population(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n, int from_partials,
                      int do_normalize, int do_mean, int do_alias) {
   if (!n) return;
-  // one particle per thread over G workgroups until G would exceed 256 (the sums are the same adjacent-pair trees for
+  // one particle per thread over G workgroups until G would exceed PFT_POP_WGS (the sums are the same adjacent-pair trees for
   // any K and G).  One workgroup with K particles per thread and no device-scope barrier was tried for the reference's
   // own 400-500 particles: slower (the two workgroups' barriers cost less than a second particle per thread).
+  static const uint32_t max_wgs = getenv("PFT_POP_MAX_WGS") ? (uint32_t)atoi(getenv("PFT_POP_MAX_WGS")) : PFT_POP_WGS;
   uint32_t K = 1;
+  while (K < 16u && (n + PFT_POPC_THREADS * K - 1) / (PFT_POPC_THREADS * K) > max_wgs) K <<= 1;
   while ((n + PFT_POPC_THREADS * K - 1) / (PFT_POPC_THREADS * K) > PFT_POPM_MAX_WGS) K <<= 1;  // n <= PFT_MAX_PARTICLES: K <= 16
   uint32_t G = 1;
   while (G * PFT_POPC_THREADS * K < n) G <<= 1;  // a power of two: the workgroups are the upper levels of the sum trees
