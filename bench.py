@@ -248,7 +248,20 @@ def main():
         if share_gpu:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            # RCCL prints a version banner to STDOUT when its first communicator comes up; stdout is reserved for the one
+            # JSON line, so the communicator is brought up (one tiny all-reduce) with file descriptor 1 pointing at stderr
+            sys.stdout.flush()
+            saved_stdout = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("nccl", device_id=dev)
+                warm = torch.zeros(1, device=dev)
+                dist.all_reduce(warm)
+                torch.cuda.synchronize()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved_stdout, 1)
+                os.close(saved_stdout)
 
     P_local = ARGS.particles_per_gpu
     sharded = world > 1 and ARGS.objects == 1  # several objects are replicas (one handle each), never sharded
