@@ -250,6 +250,7 @@ def main():
         else:
             # RCCL prints a version banner to STDOUT when its first communicator comes up; stdout is reserved for the one
             # JSON line, so the communicator is brought up (one tiny all-reduce) with file descriptor 1 pointing at stderr
+            os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")  # (and whatever it logs later)
             sys.stdout.flush()
             saved_stdout = os.dup(1)
             os.dup2(2, 1)
