@@ -143,6 +143,7 @@ void pft_aabb_support_subset(const pft_point_xyzrgba* pts, size_t n, std::vector
   // ---- every other point: the facets it sees go, the horizon is joined to it ----
   std::vector<uint32_t> vis;
   std::vector<std::pair<uint32_t, uint32_t>> horizon;
+  size_t n_alive = 4;
   for (uint32_t p = 0; p < n; p++) {
     if (p == i0 || p == i1 || p == i2 || p == i3) continue;
     vis.clear();
@@ -164,6 +165,9 @@ void pft_aabb_support_subset(const pft_point_xyzrgba* pts, size_t n, std::vector
     for (const auto& e : horizon)
       if (!add_face(e.first, e.second, p)) return all();
     if (F.size() > 400000) return all();
+    n_alive += horizon.size();
+    n_alive -= vis.size();
+    if (n_alive > n) return all();  // more than half of the points are hull vertices: nothing worth dropping
   }
 
   // ---- verification: a closed surface (every edge has its twin) that no point is outside of ----
