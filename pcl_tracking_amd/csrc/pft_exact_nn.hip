@@ -8,11 +8,14 @@
 // of two octree leaves (2 cm): counting sort of the cropped points by cell (small kernels, every iteration).  The
 // queries of an iteration fall into a few ten thousand of its cells; for each of those cells the points that can be
 // the nearest neighbour of ANY query inside it are collected once (k_ec_mark / k_ec_slots / k_ec_build: "candidate
-// lists"), and a query walks its cell's list -- about 90 candidates on the bench workload instead of the thousands a
-// per-query search of the 10 cm gate visits.  Nearest = smallest float pointSquaredDist, equal distances -> lowest
-// cloud index (upstream leaves ties to std::sort).  The per-query shell search (rings of grid rows of growing radius)
-// remains as the path for queries outside the grid and for cells that found the list pool full.  No octree is built
-// in this mode.
+// lists", about 90 candidates per query on the bench workload instead of the thousands a per-query search of the
+// 10 cm gate visits), the queries are sorted by cell (k_eq_scatter), and a wave walks ONE list for 64 queries of one cell
+// with the candidate in scalar registers (k_eq_search; k_eq_reduce sums the pairs' values per particle).  Nearest =
+// smallest float pointSquaredDist, equal distances -> lowest cloud index (upstream leaves ties to std::sort).  The
+// per-query list walk (k_likelihood_exact, PFT_EXACT_PER_QUERY=1) and the per-query shell search (rings of grid rows
+// of growing radius: queries outside the grid, cells that found the list pool full, PFT_EXACT_SHELLS_ONLY=1) remain
+// as cross-checks and fallbacks.  No octree is built in this mode.  Kernels per iteration: k_eg_* (grid, 7 launches),
+// k_ec_mark, k_ec_slots, k_ec_build, k_eq_scatter, k_eq_search, k_eq_reduce.
 #include "pft_device_utils.h"
 
 #define EG_TILE 2048u
@@ -182,6 +185,7 @@ __device__ __forceinline__ bool eg_query_cell(const PftHeader* h, float qx, floa
 #define EQ_EMPTY 0xffffffffu
 #define EQ_PROBES 48
 
+static_assert(EQ_TAB == 8192u, "eq_hash yields 13 bits");
 __device__ __forceinline__ uint32_t eq_hash(uint32_t c) { return (c * 2654435761u) >> 19; }  // 13 bits
 
 __device__ __forceinline__ uint32_t eq_insert(uint32_t* key, uint32_t c) {
