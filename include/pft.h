@@ -176,6 +176,12 @@ int pft_debug_get_ticks(pft_tracker* t, uint64_t* ticks32);
  * number of generic levels, [11] queries that used the jump table, [12] wave iterations, [13..15] sums of
  * the per-wave maxima of generic levels / fast levels / leaf size, [16..26] wave iterations by max generic */
 int pft_debug_get_descent_stats(pft_tracker* t, uint64_t* dbg32);
+/* host-only (no device needed): the positions of the reference points the bounding box of the particles' transformed
+ * clouds is taken over (A3: calcBoundingBox of the tracker that /root/reference/src/auto_tracking.cpp:691-693 runs) -- the
+ * convex hull's vertices plus the shell the float evaluation can reach; `keep` has room for n indices (ascending),
+ * *n_keep receives their number (n itself for a degenerate cloud).  Same points, same order as the library uses for a
+ * reference cloud handed to pft_set_reference in this order. */
+int pft_debug_aabb_support_subset(const pft_point_xyzrgba* pts, size_t n, uint32_t* keep, size_t* n_keep);
 /* timing experiments only: skip stages of the likelihood kernel (bit0 generic levels, bit1 leaf scan,
  * bit2 coherence); results are wrong by construction while a mask is set */
 void pft_debug_set_ablate(int mask);

@@ -92,6 +92,7 @@ SYMBOLS = [
     ("pft_debug_get_host_stat", C.c_int, [_vp, _vp]),
     ("pft_debug_get_ticks", C.c_int, [_vp, _vp]),
     ("pft_debug_get_descent_stats", C.c_int, [_vp, _vp]),
+    ("pft_debug_aabb_support_subset", C.c_int, [_vp, C.c_size_t, _vp, _vp]),
     ("pft_debug_set_ablate", None, [C.c_int]),
     ("pft_debug_likelihood_occupancy", C.c_int, []),
     ("pft_debug_normalize", C.c_int, [_vp, _vp, _sz, _P(_f64)]),

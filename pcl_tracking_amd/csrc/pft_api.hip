@@ -1300,6 +1300,15 @@ extern "C" int pft_debug_get_ticks(pft_tracker* t, uint64_t* ticks32) {
   return PFT_OK;
 }
 
+extern "C" int pft_debug_aabb_support_subset(const pft_point_xyzrgba* pts, size_t n, uint32_t* keep, size_t* n_keep) {
+  if ((!pts && n) || !keep || !n_keep) return PFT_ERR_INVALID_ARG;
+  std::vector<uint32_t> k;
+  pft_aabb_support_subset(pts, n, k);
+  for (size_t i = 0; i < k.size(); i++) keep[i] = k[i];
+  *n_keep = k.size();
+  return PFT_OK;
+}
+
 extern "C" int pft_debug_get_descent_stats(pft_tracker* t, uint64_t* dbg32) {
   if (!t || !dbg32) return PFT_ERR_INVALID_ARG;
   PftHeader h;
