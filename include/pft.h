@@ -182,9 +182,11 @@ int pft_debug_get_descent_stats(pft_tracker* t, uint64_t* dbg32);
  * *n_keep receives their number (n itself for a degenerate cloud).  Same points, same order as the library uses for a
  * reference cloud handed to pft_set_reference in this order. */
 int pft_debug_aabb_support_subset(const pft_point_xyzrgba* pts, size_t n, uint32_t* keep, size_t* n_keep);
-/* timing experiments only: skip stages of the likelihood kernel (bit0 generic levels, bit1 leaf scan,
- * bit2 coherence); results are wrong by construction while a mask is set */
+#ifdef PFT_DIAG
+/* diagnostic variant library only (tools/build_variant.py diag -DPFT_DIAG; never in libpft_hip.so): skip stages of the
+ * likelihood kernel for timing (bit0 generic levels, bit1 leaf scan, bit2 coherence); results are wrong while set */
 void pft_debug_set_ablate(int mask);
+#endif
 /* diagnostic: resident likelihood workgroups per CU according to the HIP occupancy API */
 int pft_debug_likelihood_occupancy(void);
 int pft_debug_normalize(pft_tracker* t, float* w_inout, size_t n, double* fit_ratio);

@@ -93,7 +93,6 @@ SYMBOLS = [
     ("pft_debug_get_ticks", C.c_int, [_vp, _vp]),
     ("pft_debug_get_descent_stats", C.c_int, [_vp, _vp]),
     ("pft_debug_aabb_support_subset", C.c_int, [_vp, C.c_size_t, _vp, _vp]),
-    ("pft_debug_set_ablate", None, [C.c_int]),
     ("pft_debug_likelihood_occupancy", C.c_int, []),
     ("pft_debug_normalize", C.c_int, [_vp, _vp, _sz, _P(_f64)]),
     ("pft_debug_alias", C.c_int, [_vp, _vp, _sz, _vp, _vp]),
@@ -120,6 +119,11 @@ SYMBOLS = [
     ("pft_filter_get_output", C.c_int, [_vp, _vp, _sz, _P(_sz)]),
     ("pft_filter_get_pass_indices", C.c_int, [_vp, _vp, _sz, _P(_sz)]),
     ("pft_filter_last_ms", C.c_int, [_vp, _P(_f64)]),
+]
+
+# exported by the diagnostic variant library only (tools/build_variant.py diag -DPFT_DIAG): bound when present
+DIAG_SYMBOLS = [
+    ("pft_debug_set_ablate", None, [C.c_int]),
 ]
 
 _lib = None
@@ -164,5 +168,10 @@ def load():
         f = getattr(L, name)  # AttributeError if the library does not export a declared symbol
         f.restype = res
         f.argtypes = args
+    for name, res, args in DIAG_SYMBOLS:
+        f = getattr(L, name, None)
+        if f is not None:
+            f.restype = res
+            f.argtypes = args
     _lib = L
     return L

@@ -876,11 +876,14 @@ static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32
     bool sorted = last_n > PFT_SORTED_BUILD_MIN;
     if (t->force_builder == 1) sorted = false;
     if (t->force_builder == 2) sorted = true;
-    // timing experiments only (results are wrong while set): PFT_DEBUG_SKIP_OCTREE=1 reuses the tree of the
+#ifdef PFT_DIAG
+    // diagnostic build only (results are wrong while set): PFT_DEBUG_SKIP_OCTREE=1 reuses the tree of the
     // previous build after the first 8 builds, to measure the builder's true share of a frame
     static const bool skip_env = getenv("PFT_DEBUG_SKIP_OCTREE") != nullptr;
     if (skip_env && ++t->dbg_builds > 8) {
-    } else if (sorted) {
+    } else
+#endif
+    if (sorted) {
       // 8-bit passes for 3 bits per level; one level of head-room over the last depth (k_so_scan flags an error
       // if the tree turned out deeper than the passes cover)
       // (a deeper tree than the passes cover is rebuilt by the rescue launch behind the sorted builder: the guess

@@ -401,7 +401,12 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
 template <bool DEBUG_NN>
 __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * PFT_LIK_WGS_PER_CU) / 256) void k_likelihood(PftParams prm, PftDev d, uint32_t n_particles,
                                                                 uint32_t lds_bytes, int flags) {
-  const int allow_fast = flags & 1, abl = flags >> 8;
+  const int allow_fast = flags & 1;
+#ifdef PFT_DIAG
+  const int abl = flags >> 8;  // diagnostic build only (tools/build_variant.py diag -DPFT_DIAG): stage ablation for timing
+#else
+  constexpr int abl = 0;  // the product build has no way to skip a stage
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const PftHeader* hdr = d.hdr;
   if (d.p_active) n_particles = *d.p_active;  // KLD variant: particle_num_ lives on the device
@@ -555,11 +560,14 @@ extern "C" int pft_debug_likelihood_occupancy(void) {
   return nb;
 }
 
-// timing experiments only (tools/lik_microbench.py): bit0 generic levels, bit1 leaf scan, bit2 coherence
+#ifdef PFT_DIAG
+// timing experiments only (tools/lik_microbench.py with the diagnostic variant library): bit0 generic levels, bit1 leaf
+// scan, bit2 coherence.  Not compiled into the product library.
 extern "C" void pft_debug_set_ablate(int mask) {
   if (g_allow_fast < 0) g_allow_fast = 1;
   g_allow_fast = (g_allow_fast & 0xff) | (mask << 8);
 }
+#endif
 
 void pftk_likelihood(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, bool debug_nn,
                      int num_cus) {
@@ -577,8 +585,10 @@ void pftk_likelihood(hipStream_t s, const PftParams& p, const PftDev& d, uint32_
   if (g_allow_fast < 0) {  // PFT_GENERIC_DESCENT=1: all-generic descent (A/B and parity cross-check)
     const char* e = getenv("PFT_GENERIC_DESCENT");
     g_allow_fast = (e && e[0] == '1') ? 0 : 1;
+#ifdef PFT_DIAG
     const char* a = getenv("PFT_ABLATE");  // timing experiments only: bit0 generic levels, bit1 leaf scan, bit2 coherence
     if (a) g_allow_fast |= atoi(a) << 8;
+#endif
   }
   uint32_t items = n_particles * p.nchunk;
   uint32_t grid = (uint32_t)PFT_LIK_WGS_PER_CU * (uint32_t)num_cus;

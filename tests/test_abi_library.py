@@ -27,6 +27,7 @@ def declared_functions():
             continue
         src = open(os.path.join(inc, h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        src = re.sub(r"#ifdef PFT_DIAG.*?#endif", "", src, flags=re.S)  # diagnostic variant library only
         names |= set(re.findall(r"\b(pft_[a-z0-9_]+)\s*\(", src))
     return sorted(names)
 
@@ -127,3 +128,12 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "pft_oracle" not in txt and "import oracle" not in txt, os.path.join(dirpath, f)
+
+
+def test_product_library_has_no_wrong_result_switches(lib):
+    """the stage-ablation mask and the octree-reuse switch are compiled only into the diagnostic
+    variant (-DPFT_DIAG); libpft_hip.so neither reads their environment variables nor exports the setter."""
+    blob = open(lib.LIB_PATH, "rb").read()
+    for needle in (b"PFT_ABLATE", b"SKIP_OCTREE", b"pft_debug_set_ablate"):
+        assert blob.count(needle) == 0, needle
+    assert not hasattr(lib.load(), "pft_debug_set_ablate")

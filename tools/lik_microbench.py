@@ -1,5 +1,8 @@
 """Stage shares of k_likelihood on a FIXED particle set (steady state of BASELINE configs[1]): the tracker
-runs normally, then pft_eval_weights is timed on its particles with stages ablated (timing only)."""
+runs normally, then pft_eval_weights is timed on its particles with stages ablated (timing only).  The ablation mask
+exists only in the diagnostic variant library: run as
+    python tools/build_variant.py diag -DPFT_DIAG            (here: hipcc cross-compiles)
+    PFT_LIB_PATH=$PWD/pcl_tracking_amd/_build/var_diag.so python tools/lik_microbench.py     (GPU box)"""
 import os
 import sys
 
@@ -15,6 +18,8 @@ N = int(sys.argv[3]) if len(sys.argv) > 3 else 50000
 model = scene.make_model(2048)
 cloud = scene.make_scene(N, mode="organized" if N == 307200 else "voxel")
 t = tracker.make_reference_tracker(particle_num=P, seed=1)
+if not hasattr(t._L, "pft_debug_set_ablate"):
+    sys.exit("this library has no stage ablation: build the diagnostic variant (see the docstring) and set PFT_LIB_PATH")
 t.setReferenceCloud(model)
 t.setTrans(scene.initial_trans())
 t.setInputCloud(cloud)
