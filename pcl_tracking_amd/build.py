@@ -62,7 +62,7 @@ EXAMPLES_DIR = os.path.join(_HERE, "examples")
 EXAMPLE_BIN = os.path.join(OUT_DIR, "auto_tracking_amd")
 DIST_EXAMPLE_BIN = os.path.join(OUT_DIR, "dist_tracking_amd")
 _EXAMPLE_DEPS = [os.path.join(EXAMPLES_DIR, "tracking_app.hpp")] + [
-    os.path.join(_HERE, "include", "pft", h) for h in ("particle_filter_tracker.hpp", "filters.hpp", "pcd_io.hpp", "common.hpp")]
+    os.path.join(_HERE, "include", "pft", h) for h in ("particle_filter_tracker.hpp", "filters.hpp", "pcd_io.hpp", "common.hpp", "id_exchange.hpp")]
 
 
 def _build_host_program(src, out, extra, force, verbose):

@@ -391,9 +391,17 @@ static int check_device_error(pft_tracker* t) {
   if (e & 1u) m += " [bit0] octree node capacity exceeded (more than 8 x input points + 64 words, or 2^24 nodes);";
   if (e & 2u) m += " [bit1] octree depth / bounding-box growth steps exceeded (PFT_MAX_DEPTH 30, PFT_MAX_GROW 40);";
   if (e & 4u) m += " [bit2] the one-pass crop gave up waiting for a predecessor workgroup;";
-  if (e & 16u) m += " [bit4] a device-scope barrier of the population kernel timed out (its workgroups were not co-resident);";
+  if (e & 16u)
+    m += " [bit4] a device-scope barrier of the population kernel timed out (its workgroups did not become co-resident "
+         "within the spin limit): that iteration's normalisation, weighted mean and alias table were NOT written -- the "
+         "weights, the result pose and the resampling table are those of the last completed iteration;";
   if (e & ~23u) m += " [other] " + std::to_string(e & ~23u) + ";";
-  m += " the affected iteration(s) ran without a target cloud (all likelihoods zero)";
+  if (e & 7u) m += " the iteration(s) with bit0-2 ran without a target cloud (all likelihoods zero)";
+  if (e & 16u) {  // the barrier counters of an interrupted launch are cleared before the next one (the launch resets them itself
+                  // when all its workgroups get through; this covers a launch that did not)
+    hipStreamSynchronize(t->stream);
+    hipMemsetAsync(reinterpret_cast<char*>(t->d_hdr) + offsetof(PftHeader, pop_bar), 0, sizeof(((PftHeader*)nullptr)->pop_bar), t->stream);
+  }
   t->err = m;
   return (e & (4u | 16u)) ? PFT_ERR_HIP : PFT_ERR_CAPACITY;
 }
@@ -786,7 +794,8 @@ static void stage_aabb(pft_tracker* t, const PftDev& d, uint32_t np, bool finali
 // (cross-check -- identical bits --, A/B timing).  The KLD variant, whose resample is a grid-wide loop of its own, and the
 // first iteration after pft_set_particles / init take the separate kernels.
 static void stage_resample_aabb(pft_tracker* t, bool finalize) {
-  static const bool split = getenv("PFT_SPLIT_RESAMPLE") != nullptr || getenv("PFT_RESAMPLE_ONE_LANE") != nullptr;
+  // (read per call, not latched: tests/test_gpu_parity.py toggles them inside one process)
+  const bool split = getenv("PFT_SPLIT_RESAMPLE") != nullptr || getenv("PFT_RESAMPLE_ONE_LANE") != nullptr;
   if (!t->prm.kld && t->changed && !split) {
     sync_dev(t);
     uint32_t nparts;
@@ -922,24 +931,38 @@ extern "C" int pft_compute(pft_tracker* t) {
   // graph updates the instantiated one in place (kernel arguments such as the epochs and the particle-buffer parity
   // change from frame to frame, the node sequence only when the builder choice does: then it is instantiated anew).
   // The first frames run directly: they set the kernels' one-time attributes, which must not happen during capture.
-  const bool graphed = t->use_graph && t->changed && !t->prof && t->graph_frames++ >= 2u &&
-                       hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-  for (int it = 0; it < t->cfg.iteration_num; it++) {
-    stage_resample_aabb(t, false);
-    // KLD variant: launches are sized for the capacity, the kernels take particle_num_ from PftHeader::p_active
-    const uint32_t np = t->prm.kld ? t->Pcap : t->prm.P_local;
-    stage_crop_octree_likelihood(t, t->dev, np, false, true);
-    {
-      ProfScope ps(t, PFT_K_POPULATION);
-      // raw weights from the partial sums, then weight()'s normalizeWeight(); use_change_detector_ == false
-      // => changed_ = true => update(); the alias prefix form feeds the next resample: one launch
-      pftk_population(t->stream, t->prm, t->dev, t->prm.kld ? t->Pcap : t->prm.P_total, 1, 1, 1, 1);
+  // Nothing that allocates or sets a one-time kernel attribute may run during capture: the exact-NN mode (its query
+  // arrays grow with np * M inside the stage) is never captured, and a capture that fails for any other reason -- a
+  // builder or rescue kernel whose attribute is set on first use, say -- switches the handle back to direct launches
+  // and runs THIS frame directly: the host-side state the recorded pass advanced is put back first.
+  auto run_iterations = [&]() {
+    for (int it = 0; it < t->cfg.iteration_num; it++) {
+      stage_resample_aabb(t, false);
+      // KLD variant: launches are sized for the capacity, the kernels take particle_num_ from PftHeader::p_active
+      const uint32_t np = t->prm.kld ? t->Pcap : t->prm.P_local;
+      stage_crop_octree_likelihood(t, t->dev, np, false, true);
+      {
+        ProfScope ps(t, PFT_K_POPULATION);
+        // raw weights from the partial sums, then weight()'s normalizeWeight(); use_change_detector_ == false
+        // => changed_ = true => update(); the alias prefix form feeds the next resample: one launch
+        pftk_population(t->stream, t->prm, t->dev, t->prm.kld ? t->Pcap : t->prm.P_total, 1, 1, 1, 1);
+      }
+      t->changed = true;
     }
-    t->changed = true;
-  }
-  if (graphed) {
+  };
+  const bool graphed = t->use_graph && !t->cfg.exact_nearest && t->changed && !t->prof && t->graph_frames++ >= 2u;
+  if (!graphed) {
+    run_iterations();
+  } else {
+    const int cur0 = t->cur;
+    const uint32_t epoch0 = t->resample_epoch, crop0 = t->crop_epoch, grid0 = t->dev.bbox_grid;
+    const pft_point_xyzrgba* raw0 = t->raw_pending;
+    hipError_t ge = hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal);
     hipGraph_t g = nullptr;
-    hipError_t ge = hipStreamEndCapture(t->stream, &g);
+    if (ge == hipSuccess) {
+      run_iterations();
+      ge = hipStreamEndCapture(t->stream, &g);
+    }
     if (ge == hipSuccess && g) {
       bool ready = false;
       if (t->graph_exec) {
@@ -958,11 +981,24 @@ extern "C" int pft_compute(pft_tracker* t) {
         ready = ge == hipSuccess;
       }
       if (ready) ge = hipGraphLaunch(t->graph_exec, t->stream);
-      hipGraphDestroy(g);
+    } else if (ge == hipSuccess) {
+      ge = hipErrorUnknown;
     }
-    if (ge != hipSuccess) {
-      t->err = std::string("frame graph: ") + hipGetErrorString(ge);
-      return PFT_ERR_HIP;
+    if (g) hipGraphDestroy(g);
+    if (ge != hipSuccess) {  // none of the frame's work was issued: back to direct launches, for this frame and for good
+      (void)hipGetLastError();
+      if (t->graph_exec) {
+        hipGraphExecDestroy(t->graph_exec);
+        t->graph_exec = nullptr;
+      }
+      t->use_graph = false;
+      t->cur = cur0;
+      t->resample_epoch = epoch0;
+      t->crop_epoch = crop0;
+      t->dev.bbox_grid = grid0;
+      t->raw_pending = raw0;
+      sync_dev(t);
+      run_iterations();
     }
   }
   hipError_t e = hipGetLastError();

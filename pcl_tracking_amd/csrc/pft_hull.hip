@@ -9,7 +9,7 @@
 // float value stays below the float value of the hull vertex that is extreme in the direction concerned, for every
 // rotation row r (|r| <= 1 + 1e-6), and min / max over the subset equal min / max over the cloud bit for bit.
 //
-// The hull is built incrementally in double (every point against every facet: a reference cloud is a few thousand
+// The hull is built incrementally in double (every point against every LIVE facet: a reference cloud is a few thousand
 // points, once per pft_set_reference) and then VERIFIED -- every point inside every facet, every edge shared by exactly
 // two facets -- before anything is dropped; a cloud that is degenerate (planar, collinear, tiny, non-finite
 // coordinates) or fails the verification keeps all its points.
@@ -164,10 +164,26 @@ void pft_aabb_support_subset(const pft_point_xyzrgba* pts, size_t n, std::vector
     if (horizon.size() < 3) return all();
     for (const auto& e : horizon)
       if (!add_face(e.first, e.second, p)) return all();
-    if (F.size() > 400000) return all();
     n_alive += horizon.size();
     n_alive -= vis.size();
     if (n_alive > n) return all();  // more than half of the points are hull vertices: nothing worth dropping
+    // dead facets are dropped from the list once they outnumber the live ones, so that a point is tested against O(live
+    // facets): a shell-like cloud of 8 192 points costs ~2e7 plane tests up to the bail-out above instead of ~1e8
+    if (F.size() > 2 * n_alive + 256) {
+      std::vector<uint32_t> remap(F.size(), 0xffffffffu);
+      std::vector<Face> G;
+      G.reserve(2 * n_alive + 512);
+      for (uint32_t f = 0; f < F.size(); f++)
+        if (F[f].alive) {
+          remap[f] = (uint32_t)G.size();
+          G.push_back(F[f]);
+        }
+      F.swap(G);
+      for (auto& kv : edge) {  // (the edges of dead facets were erased above: every entry names a live one)
+        if (remap[kv.second] == 0xffffffffu) return all();
+        kv.second = remap[kv.second];
+      }
+    }
   }
 
   // ---- verification: a closed surface (every edge has its twin) that no point is outside of ----

@@ -609,7 +609,7 @@ static AliasView alias_view(const PftDev& d, uint32_t n) {
   return v;
 }
 void pftk_resample(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t epoch, pft_particle* out) {
-  static const bool one_lane = getenv("PFT_RESAMPLE_ONE_LANE") != nullptr;  // A/B and cross-check: the one-lane-per-particle kernel
+  const bool one_lane = getenv("PFT_RESAMPLE_ONE_LANE") != nullptr;  // A/B and cross-check: the one-lane-per-particle kernel (read per call)
   if (one_lane)
     hipLaunchKernelGGL(k_resample<false>, dim3(cdiv(p.P_local, 256)), dim3(256), 0, s, p, d.part_all,
                        alias_view(d, p.P_total), (const int32_t*)nullptr, (const double*)nullptr, d.hdr, epoch, out,

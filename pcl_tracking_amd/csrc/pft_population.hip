@@ -43,6 +43,7 @@ struct PopcSh {
   double red[10][4];
   uint32_t u[4];
   double da[4], db[4];
+  uint32_t timed_out;  // grid_barrier's verdict for the workgroup
 };
 
 // every thread receives the workgroup's adjacent-pair tree sum of each of its NV values
@@ -88,11 +89,15 @@ __device__ __forceinline__ double pub_load(const double* p) {
 // Device-scope barrier of the launch's G co-resident workgroups (G <= 256 on a 256-CU part; they are tiny).  Thread 0
 // of a workgroup has published the workgroup's values with pub_store; it waits for those atomics to be performed,
 // arrives, and polls with a bounded spin: a launch that could not get all its workgroups resident in time raises error
-// bit 4 instead of hanging the GPU.
-__device__ __forceinline__ void grid_barrier(PftHeader* hdr, int k, uint32_t G) {
+// bit 4 instead of hanging the GPU.  Returns false (to every thread of the workgroup) when the barrier timed out here or
+// in any other workgroup: the caller then writes NOTHING further -- no weights, no mean, no alias lists from values that
+// did not arrive -- so the population keeps the state of the last good launch and the host reports the flag.  (The
+// workgroups are tiny -- G <= 128 x 256 threads, ~400 B of LDS -- and fit beside anything but a kernel that holds every
+// CU's whole LDS; they then start as that kernel's workgroups retire, which the spin limit, ~0.4 s, outlasts.)
+__device__ __forceinline__ bool grid_barrier(PftHeader* hdr, int k, uint32_t G, uint32_t* sh_flag) {
   if (G <= 1u) {
     __syncthreads();
-    return;
+    return true;
   }
   if (threadIdx.x == 0) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -106,8 +111,10 @@ __device__ __forceinline__ void grid_barrier(PftHeader* hdr, int k, uint32_t G) 
       __builtin_amdgcn_s_sleep(PFT_POPC_POLL_SLEEP);
     }
     asm volatile("" ::: "memory");
+    *sh_flag = __hip_atomic_load(&hdr->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 16u;
   }
   __syncthreads();
+  return *sh_flag == 0u;
 }
 
 template <int K>
@@ -120,6 +127,7 @@ __device__ __forceinline__ void population_body(const PftParams& prm, const PftD
   const uint32_t i0 = (g * PFT_POPC_THREADS + tid) * (uint32_t)K;
   double* part = d.pop_part;
 
+  bool timed_out = false;
   STAMP(0);
   // ---- phase 0: raw (or given) weights ----
   float wr[K];
@@ -163,7 +171,7 @@ __device__ __forceinline__ void population_body(const PftParams& prm, const PftD
       pub_store(&part[g * 16 + PP_MIN], fmin(fmin(S.da[0], S.da[1]), fmin(S.da[2], S.da[3])));
       pub_store(&part[g * 16 + PP_MAX], fmax(fmax(S.db[0], S.db[1]), fmax(S.db[2], S.db[3])));
     }
-    grid_barrier(hdr, 0, G);
+    bool live = grid_barrier(hdr, 0, G, &S.timed_out);
     STAMP(1);
     // ---- phase 1: the exponential, the weight sum ----
     wmin = tid < G ? pub_load(&part[tid * 16 + PP_MIN]) : DBL_MAX;
@@ -197,7 +205,7 @@ __device__ __forceinline__ void population_body(const PftParams& prm, const PftD
     double s1[1] = {thread_tree_sum<K>(sv)};
     wg_tree_sum<1>(s1, S);
     if (tid == 0) pub_store(&part[g * 16 + PP_SUM], s1[0]);
-    grid_barrier(hdr, 1, G);
+    live = grid_barrier(hdr, 1, G, &S.timed_out) && live;
     STAMP(2);
     // ---- phase 2: normalise ----
     s1[0] = tid < G ? pub_load(&part[tid * 16 + PP_SUM]) : 0.0;
@@ -208,12 +216,15 @@ __device__ __forceinline__ void population_body(const PftParams& prm, const PftD
     for (int j = 0; j < K; j++) {
       if (i0 + j < n) {
         wr[j] = (sum != 0.0) ? wr[j] / fs : 1.0f / (float)n;
-        P[i0 + j].weight = wr[j];
+        if (live) P[i0 + j].weight = wr[j];
       }
     }
+    timed_out = !live;
   }
 
   // ---- weighted-pose sums and alias partition totals of this workgroup ----
+  // (after a timed-out barrier the workgroups still meet at the remaining barriers and at the counter reset below, but
+  // write nothing: `timed_out` is workgroup-uniform)
   uint32_t cntL = 0;
   double defs = 0.0, excs = 0.0;
   if (do_mean || do_alias) {
@@ -259,7 +270,7 @@ __device__ __forceinline__ void population_body(const PftParams& prm, const PftD
       pub_store(&part[g * 16 + PP_DEF], tot[7]);
       pub_store(&part[g * 16 + PP_EXC], tot[8]);
     }
-    grid_barrier(hdr, 2, G);
+    timed_out = !grid_barrier(hdr, 2, G, &S.timed_out) || timed_out;
     STAMP(3);
     // ---- phase 3: every workgroup combines the workgroups' values the same way ----
     double fin[10];
@@ -271,7 +282,7 @@ __device__ __forceinline__ void population_body(const PftParams& prm, const PftD
     fin[7] = after_me ? pub_load(&part[tid * 16 + PP_DEF]) : 0.0;
     fin[8] = after_me ? pub_load(&part[tid * 16 + PP_EXC]) : 0.0;
     wg_tree_sum<10>(fin, S);
-    if (do_mean && g == 0 && tid == 0) {
+    if (do_mean && g == 0 && tid == 0 && !timed_out) {
       pft_particle orig = hdr->rep, r;
       r.x = (float)fin[0]; r.y = (float)fin[1]; r.z = (float)fin[2]; r.w = 1.0f;
       r.roll = (float)fin[3]; r.pitch = (float)fin[4]; r.yaw = (float)fin[5];
@@ -283,7 +294,7 @@ __device__ __forceinline__ void population_body(const PftParams& prm, const PftD
       hdr->rep = r;
       hdr->motion = m;
     }
-    if (do_alias) {
+    if (do_alias && !timed_out) {
       if (g == 0 && tid == 0) {
         hdr->alias_m = (uint32_t)fin[9];
         hdr->alias_nh = n - (uint32_t)fin[9];

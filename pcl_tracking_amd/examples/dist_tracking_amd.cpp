@@ -16,8 +16,14 @@
 //   dist_tracking_amd <model> <frame0> [frame1 ...] [--particles N_TOTAL] [--seed S] [--model-leaf L] [--id-file PATH]
 //
 // Launch: one process per GPU with RANK / WORLD_SIZE / LOCAL_RANK in the environment (as torch.distributed.run or mpirun
-// -x would set them; unset = a single rank).  The ncclUniqueId travels through a file (--id-file, default
-// /tmp/pft_nccl_id.<MASTER_PORT or 0>): rank 0 writes it, the others wait for it -- one node, shared /tmp.
+// -x would set them; unset = a single rank).  The ncclUniqueId travels through a file: --id-file PATH, or
+// /tmp/pft_nccl_id.<MASTER_PORT> (several ranks need one of the two: there is no shared default path).  The file holds a
+// record that a reader accepts only if it belongs to THIS launch and its publisher still runs (pft/id_exchange.hpp): a
+// file left by a crashed run, or by another launch, is never taken for the id.
+// Failures: a rank whose pft_* call fails keeps issuing the frame's collectives (so nobody blocks in one), and the ranks
+// agree on the frame's status with a one-int all-reduce at the frame's end -- all of them stop together.  A rank waits for
+// its stream with a time-out and polls ncclCommGetAsyncError; a dead peer or a failed collective ends in ncclCommAbort,
+// not in a hang.
 // With one rank the phases and collectives still run, and the result equals pft_compute()'s bit for bit (that is the
 // -m gpu test; the 8-GPU run belongs to the driver's node).
 #include <hip/hip_runtime.h>
@@ -28,6 +34,7 @@
 #include <cstdlib>
 #include <thread>
 
+#include "pft/id_exchange.hpp"
 #include "tracking_app.hpp"
 
 using namespace app;
@@ -48,7 +55,7 @@ using namespace app;
       return 1;                                                                         \
     }                                                                                   \
   } while (0)
-#define PFTOK(call)                                                                                              \
+#define PFTOK(call) /* set-up only (before the first collective): a failing rank may simply leave */                                                                                             \
   do {                                                                                                           \
     int s_ = (call);                                                                                             \
     if (s_ != PFT_OK) {                                                                                          \
@@ -64,28 +71,42 @@ static int env_int(const char* name, int dflt) {
   return v && *v ? std::atoi(v) : dflt;
 }
 
-// rank 0 publishes the communicator id in a file (written under a temporary name, then renamed: readers never see half of it)
+// rank 0 publishes the communicator id, the others wait for THIS launch's record (pft/id_exchange.hpp)
 static bool exchange_id(ncclUniqueId* id, int rank, int world, const std::string& path) {
   if (world == 1) return ncclGetUniqueId(id) == ncclSuccess;
+  const uint64_t nonce = pft::launch_nonce();
   if (rank == 0) {
     if (ncclGetUniqueId(id) != ncclSuccess) return false;
-    const std::string tmp = path + ".tmp";
-    FILE* f = std::fopen(tmp.c_str(), "wb");
-    if (!f) return false;
-    const bool ok = std::fwrite(id, sizeof(*id), 1, f) == 1;
-    std::fclose(f);
-    return ok && std::rename(tmp.c_str(), path.c_str()) == 0;
+    return pft::publish_id(path, id, sizeof(*id), nonce);
   }
-  for (int tries = 0; tries < 6000; tries++) {  // up to a minute
-    FILE* f = std::fopen(path.c_str(), "rb");
-    if (f) {
-      const bool ok = std::fread(id, sizeof(*id), 1, f) == 1;
-      std::fclose(f);
-      if (ok) return true;
-    }
-    std::this_thread::sleep_for(std::chrono::milliseconds(10));
-  }
+  pft::IdCheck why;
+  if (pft::await_id(path, id, sizeof(*id), nonce, 60000, &why)) return true;
+  std::fprintf(stderr, "rank %d: %s: %s\n", rank, path.c_str(), pft::id_check_string(why));
   return false;
+}
+
+// wait for the rank's stream without blocking forever: a peer that died or a collective that failed shows up as an
+// asynchronous communicator error or as a time-out
+static bool wait_stream(ncclComm_t comm, hipStream_t stream, int timeout_s) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(stream);
+    if (q == hipSuccess) return true;
+    if (q != hipErrorNotReady) {
+      std::fprintf(stderr, "rank %d: stream: %s\n", g_rank, hipGetErrorString(q));
+      return false;
+    }
+    ncclResult_t ar = ncclSuccess;
+    if (ncclCommGetAsyncError(comm, &ar) != ncclSuccess || ar != ncclSuccess) {
+      std::fprintf(stderr, "rank %d: communicator: %s\n", g_rank, ncclGetErrorString(ar));
+      return false;
+    }
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s)) {
+      std::fprintf(stderr, "rank %d: the frame did not finish within %d s (a peer gone?)\n", g_rank, timeout_s);
+      return false;
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
 }
 
 int main(int argc, char** argv) {
@@ -110,7 +131,13 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "rank %d / world %d: the particle count (%d) must divide over the ranks\n", rank, world, opt.particles);
     return 2;
   }
-  if (id_file.empty()) id_file = "/tmp/pft_nccl_id." + std::to_string(env_int("MASTER_PORT", 0));
+  if (id_file.empty()) {
+    if (world > 1 && !std::getenv("MASTER_PORT")) {
+      std::fprintf(stderr, "rank %d: %d ranks need a launch-unique rendezvous: set MASTER_PORT or pass --id-file PATH\n", rank, world);
+      return 2;
+    }
+    id_file = "/tmp/pft_nccl_id." + std::to_string(env_int("MASTER_PORT", 0));
+  }
 
   int ndev = 0;
   HIPOK(hipGetDeviceCount(&ndev));
@@ -152,24 +179,60 @@ int main(int argc, char** argv) {
   HIPOK(hipMalloc(reinterpret_cast<void**>(&d_gathered), P * sizeof(pft_particle)));
   PFTOK(pft_dist_bind(h, d_bbox6, d_shard, d_gathered));
 
+  int* d_status = nullptr;
+  HIPOK(hipMalloc(reinterpret_cast<void**>(&d_status), sizeof(int)));
+
+  // From here on the ranks are tied together by collectives.  A pft_* failure is remembered and the frame's collectives
+  // are still issued; a communication failure aborts the communicator.
+  bool failed = false;
+  auto soft = [&](int s_, const char* what) {
+    if (s_ != PFT_OK && !failed) {
+      failed = true;
+      std::fprintf(stderr, "rank %d: %s: %s (%s)\n", rank, what, pft_status_string(s_), pft_last_error_string(h));
+    }
+  };
+  auto hard = [&](const char* what, const char* msg) {
+    std::fprintf(stderr, "rank %d: %s: %s\n", rank, what, msg);
+    ncclCommAbort(comm);
+    return 1;
+  };
+#define COLL(call)                                                        \
+  do {                                                                    \
+    ncclResult_t r_ = (call);                                             \
+    if (r_ != ncclSuccess) return hard(#call, ncclGetErrorString(r_));    \
+  } while (0)
+
   const int iterations = tracker.getIterationNum();
   for (size_t f = 1; f < files.size(); f++) {
     Cloud::Ptr cloud = loadCloud(files[f]);
     if (cloud->empty()) {
       std::fprintf(stderr, "rank %d: frame %zu is empty\n", rank, f);
+      failed = true;
+    }
+    if (!failed) soft(pft_set_input(h, cloud->points.data(), cloud->points.size()), "pft_set_input");
+    if (!failed) soft(pft_dist_begin_frame(h), "pft_dist_begin_frame");  // initParticles on the first frame
+    for (int it = 0; it < iterations; it++) {
+      if (!failed) soft(pft_dist_phase_a(h, it), "pft_dist_phase_a");
+      COLL(ncclAllReduce(d_bbox6, d_bbox6, 6, ncclFloat, ncclMax, comm, stream));
+      if (!failed) soft(pft_dist_phase_b(h), "pft_dist_phase_b");
+      COLL(ncclAllGather(d_shard, d_gathered, P_local * sizeof(pft_particle) / sizeof(float), ncclFloat, comm, stream));
+      if (!failed) soft(pft_dist_phase_c(h), "pft_dist_phase_c");
+    }
+    if (!wait_stream(comm, stream, 120)) return hard("frame", "stream wait failed");
+    ParticleT result;
+    if (!failed) soft(pft_get_result(h, &result), "pft_get_result");  // also reports device-side failures of the frame
+    // the ranks agree on the frame: 1 = fine everywhere
+    int ok = failed ? 0 : 1;
+    if (hipMemcpyAsync(d_status, &ok, sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess) return hard("status", "copy");
+    COLL(ncclAllReduce(d_status, d_status, 1, ncclInt, ncclMin, comm, stream));
+    if (hipMemcpyAsync(&ok, d_status, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess) return hard("status", "copy");
+    if (!wait_stream(comm, stream, 120)) return hard("status", "stream wait failed");
+    if (!ok) {
+      if (!failed) std::fprintf(stderr, "rank %d: frame %zu failed on another rank: stopping with it\n", rank, f);
+      ncclCommDestroy(comm);
+      if (rank == 0 && world > 1) ::unlink(id_file.c_str());
       return 1;
     }
-    PFTOK(pft_set_input(h, cloud->points.data(), cloud->points.size()));
-    PFTOK(pft_dist_begin_frame(h));  // initParticles on the first frame
-    for (int it = 0; it < iterations; it++) {
-      PFTOK(pft_dist_phase_a(h, it));
-      NCCLOK(ncclAllReduce(d_bbox6, d_bbox6, 6, ncclFloat, ncclMax, comm, stream));
-      PFTOK(pft_dist_phase_b(h));
-      NCCLOK(ncclAllGather(d_shard, d_gathered, P_local * sizeof(pft_particle) / sizeof(float), ncclFloat, comm, stream));
-      PFTOK(pft_dist_phase_c(h));
-    }
-    ParticleT result;
-    PFTOK(pft_get_result(h, &result));  // synchronises the stream; also reports device-side failures of the frame
     if (rank == 0) {
       float centroid[4];
       v.objectPosition(0, result, centroid);
@@ -179,6 +242,7 @@ int main(int argc, char** argv) {
   HIPOK(hipStreamSynchronize(stream));
   NCCLOK(ncclCommDestroy(comm));
   if (rank == 0 && world > 1) ::unlink(id_file.c_str());
+  hipFree(d_status);
   hipFree(d_bbox6);
   hipFree(d_shard);
   hipFree(d_gathered);

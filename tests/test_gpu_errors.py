@@ -118,6 +118,37 @@ def test_crop_timeout_flag_is_reported_by_every_sync_point(gpu, data, call):
     assert p["weight"].max() > 2.0 / len(p)
 
 
+def test_population_barrier_timeout_writes_nothing_and_is_named(gpu, data):
+    """bit4: a device-scope barrier of the population kernel that times out must not leave weights, mean and
+    alias table computed from values that never arrived.  The flag cannot be provoked on an idle GPU (the workgroups are
+    co-resident at once), so it is injected behind the crop launch: every workgroup of the population launch then sees it
+    at its first barrier, as it would after a real time-out elsewhere in the grid."""
+    from pcl_tracking_amd._lib import PftError
+
+    t = fresh(gpu, data, P=2048)  # 8 workgroups: the barriers are real
+    t.compute()
+    t.synchronize()
+    before = t.getResult()
+    w_before = t.getParticles()["weight"].copy()
+    assert w_before.max() > 2.0 / 2048
+    t.debugInjectError(16)
+    t.compute()
+    with pytest.raises(PftError) as e:
+        t.getResult()
+    msg = str(e.value)
+    assert e.value.status == 5 and "bit4" in msg and "NOT written" in msg, msg
+    assert "without a target cloud" not in msg  # that sentence belongs to bits 0-2
+    # the first iteration of that frame wrote nothing; its second iteration was clean, so the handle is consistent again
+    after = t.getResult()
+    for k in KEYS:
+        assert np.isfinite(after[k])
+    t.compute()
+    t.synchronize()
+    p = t.getParticles()
+    assert abs(float(p["weight"].sum()) - 1.0) < 1e-3 and p["weight"].max() > 2.0 / len(p)
+    assert abs(t.getResult()["x"] - before["x"]) < 0.05
+
+
 def test_eval_weights_reports_the_flag(gpu, data):
     from pcl_tracking_amd._lib import PftError
 

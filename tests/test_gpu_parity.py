@@ -929,3 +929,54 @@ def test_bounding_box_hull_shell_random_clouds(gpu, data, monkeypatch):
             t.setInputCloud(data["scene"][:1000])
             boxes.append(np.stack([t.evalWeights(p[a:a + 256])["bbox"] for a in range(0, P, 256)]))
         np.testing.assert_array_equal(boxes[0], boxes[1], err_msg="case %d kind %d n %d scale %g" % (case, kind, n, scale))
+
+
+@pytest.mark.parametrize("kind", ["scan", "planar"])
+def test_fused_resample_box_equals_the_separate_launches(gpu, data, kind, monkeypatch):
+    """pft_compute's default steady-state iteration is ONE launch for resample + pose -> matrix + box partials
+    (k_resample4<BOX>); PFT_SPLIT_RESAMPLE=1 takes k_resample4 + k_aabb and PFT_RESAMPLE_ONE_LANE=1 the one-lane resample
+    kernel.  All three must leave the same bounding box, the same crop and the same particles, bit for bit -- also for a
+    reference whose box support set is too large for the fused form ("planar": a degenerate cloud keeps all 2 048 points,
+    more than PFT_BOX_FUSED_MAX), which then falls back to the separate launches by itself."""
+    import ctypes as C
+
+    if kind == "scan":
+        m = data["model"]
+    else:
+        rng = np.random.default_rng(5)
+        m = data["model"].copy()
+        m["y"] = np.float32(0.03125)
+        m["x"] = rng.uniform(-0.2, 0.2, len(m)).astype(np.float32)
+        m["z"] = rng.uniform(-0.15, 0.15, len(m)).astype(np.float32)
+    runs = []
+    for env in (None, "PFT_SPLIT_RESAMPLE", "PFT_RESAMPLE_ONE_LANE"):
+        for k in ("PFT_SPLIT_RESAMPLE", "PFT_RESAMPLE_ONE_LANE"):
+            monkeypatch.delenv(k, raising=False)
+        if env:
+            monkeypatch.setenv(env, "1")
+        t = gpu.make_reference_tracker(particle_num=1024, seed=3)
+        t.setReferenceCloud(m)
+        t.setTrans(scene.initial_trans())
+        t.setInputCloud(data["scene"])
+        frames = []
+        for _ in range(3):
+            t.compute()
+            t.synchronize()
+            bbox = np.zeros(6, np.float32)
+            t._check(t._L.pft_debug_get_bbox(t._h, bbox.ctypes.data_as(C.c_void_p)))
+            n = C.c_size_t()
+            t._check(t._L.pft_debug_get_crop(t._h, None, 0, C.byref(n)))
+            idx = np.zeros(n.value, np.int32)
+            t._check(t._L.pft_debug_get_crop(t._h, idx.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+            frames.append((bbox, idx, t.getParticles().copy(), t.getResult().copy()))
+        runs.append(frames)
+        if env is None:
+            m_sub, m_all = _box_points(t)
+            assert (m_sub <= 256) == (kind == "scan"), (kind, m_sub)
+    for other in runs[1:]:
+        for (b0, i0, p0, r0), (b1, i1, p1, r1) in zip(runs[0], other):
+            np.testing.assert_array_equal(b0, b1)
+            np.testing.assert_array_equal(i0, i1)
+            assert p0.tobytes() == p1.tobytes()
+            assert r0.tobytes() == r1.tobytes()
+            assert len(i0) > 100

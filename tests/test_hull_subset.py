@@ -131,3 +131,36 @@ def test_the_subset_of_a_lattice_cloud_is_still_exact():
     a, b = boxes(xyz, R), boxes(xyz[keep], R)
     np.testing.assert_array_equal(a[0], b[0])
     np.testing.assert_array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("kind", ["sphere", "thick_shell", "ball"])
+def test_largest_reference_cloud_is_bounded_in_time_and_exact(kind):
+    """8 192 points (the size limit of the subset search) with MANY hull vertices -- a sphere bails out (more than
+    half of the points are vertices: all are kept), a thick shell and a ball do not -- must not stall pft_set_reference:
+    dead facets are compacted away, so a point is tested against the live facets only.  The box stays exact."""
+    import time
+
+    rng = np.random.default_rng(11)
+    n = 8192
+    v = rng.normal(0, 1, (n, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    if kind == "sphere":
+        xyz = v * 0.3
+    elif kind == "thick_shell":
+        xyz = v * rng.uniform(0.2, 0.3, (n, 1))
+    else:
+        xyz = v * (rng.uniform(0, 1, (n, 1)) ** (1 / 3)) * 0.3
+    t0 = time.perf_counter()
+    keep = support_subset(cloud(xyz))
+    dt = time.perf_counter() - t0
+    assert dt < 5.0, dt  # (0.1 - 0.6 s here; the un-compacted facet list took an order of magnitude longer on the sphere)
+    if kind == "sphere":
+        assert len(keep) == n
+    else:
+        assert len(keep) < n // 2
+    R = rotations(rng, 300)
+    lo_all, hi_all = boxes(xyz, R)
+    lo_sub, hi_sub = boxes(xyz[keep], R)
+    np.testing.assert_array_equal(lo_all, lo_sub)
+    np.testing.assert_array_equal(hi_all, hi_sub)
+    print(kind, "kept", len(keep), "of", n, "in %.2f s" % dt)
