@@ -826,9 +826,10 @@ static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32
     if (++t->crop_epoch == 0) t->crop_epoch = 1;
     pftk_crop(t->stream, t->prm, d, bbox_from_partials, t->crop_epoch, t->raw_pending);
     t->raw_pending = nullptr;
-    if (t->inject_error) {  // test hook: what a failing crop / builder would leave behind
-      hipLaunchKernelGGL(k_inject_error, dim3(1), dim3(1), 0, t->stream, t->d_hdr, t->inject_error);
-      t->inject_error = 0;
+    if (t->inject_error & ~16u) {  // test hook: what a failing crop / builder would leave behind (bit 4 belongs to the
+                                   // population launch: pft_compute raises it there)
+      hipLaunchKernelGGL(k_inject_error, dim3(1), dim3(1), 0, t->stream, t->d_hdr, t->inject_error & ~16u);
+      t->inject_error &= 16u;
     }
   }
   if (t->cfg.exact_nearest) {  // NearestPairPointCloudCoherence: uniform grid + true nearest neighbour, no octree
@@ -941,6 +942,10 @@ extern "C" int pft_compute(pft_tracker* t) {
       // KLD variant: launches are sized for the capacity, the kernels take particle_num_ from PftHeader::p_active
       const uint32_t np = t->prm.kld ? t->Pcap : t->prm.P_local;
       stage_crop_octree_likelihood(t, t->dev, np, false, true);
+      if (t->inject_error & 16u) {  // test hook: a population barrier that timed out in some workgroup
+        hipLaunchKernelGGL(k_inject_error, dim3(1), dim3(1), 0, t->stream, t->d_hdr, 16u);
+        t->inject_error &= ~16u;
+      }
       {
         ProfScope ps(t, PFT_K_POPULATION);
         // raw weights from the partial sums, then weight()'s normalizeWeight(); use_change_detector_ == false

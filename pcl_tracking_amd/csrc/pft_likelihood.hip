@@ -398,6 +398,13 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
   }
 }
 
+#ifndef PFT_LIK_REFILL
+#define PFT_LIK_REFILL 0  // 1: the while-while work item of pft_likelihood_refill.h (measured experiment, not the product)
+#endif
+#if PFT_LIK_REFILL
+#include "pft_likelihood_refill.h"
+#endif
+
 template <bool DEBUG_NN>
 __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * PFT_LIK_WGS_PER_CU) / 256) void k_likelihood(PftParams prm, PftDev d, uint32_t n_particles,
                                                                 uint32_t lds_bytes, int flags) {
@@ -522,7 +529,11 @@ __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * 
   } else if (words_in_lds && leaf16) {  // node words addressed as LDS (ds_read), not through a generic pointer
     const uint32_t* W = lwords;
     if (fast)
+#if PFT_LIK_REFILL
+      likelihood_items_refill<DEBUG_NN>(prm, d, cx, W, n_particles, D, n_crop);
+#else
       likelihood_items<true, true, DEBUG_NN, 1>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+#endif
     else if (use_tab)
       likelihood_items<true, false, DEBUG_NN, 1>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
     else
