@@ -431,6 +431,12 @@ int orc_octree_approx_nearest(const orc_octree_t* t, const orc_point_t* q, int* 
     const void* child = node->child[min_child_idx];
     if (tree_depth < t->depth) {
       node = (const oc_branch*)child;
+      /* U10 (switch point): the key handed to the next level is the MIN child's key
+       * (`minChildKey`, as PCL 1.8.0's octree_search.hpp is recalled).  Upstream history also holds a version that
+       * passed `new_key` -- the key of the LAST existing child iterated, i.e. of the highest set bit of the child mask --
+       * whose voxel centres at the next level then belong to another cell.  That variant would read
+       * `kx = nk_last_x; ...` here (and the device: pft_likelihood.hip, the jx / jy / jz update of the generic level).
+       * Not decidable offline; min-child is implemented on both sides. */
       kx = mkx; ky = mky; kz = mkz;
       continue;
     }

@@ -51,7 +51,8 @@ _cache = {}
 def model3():
     if "model" not in _cache:
         assert len(scene._visible_faces(scene.MODEL_DIMS, POSE3)) == 3
-        _cache["model"] = scene.make_model(2048, view_pose=POSE3, return_offset=True)
+        # 1 024 model points: the CPU oracle is what this test waits for (8 seeds x 32 frames x 8 192 particles)
+        _cache["model"] = scene.make_model(1024, view_pose=POSE3, return_offset=True)
     return _cache["model"]
 
 
