@@ -170,7 +170,8 @@ int pft_debug_inject_error(pft_tracker* t, uint32_t bits);
 /* the pinned status block: [0] last crop size, [1] last depth, [2] flags of the last failed iteration, [3] unreported flags */
 int pft_debug_get_host_stat(pft_tracker* t, uint32_t out4[4]);
 /* wall-clock stamps (100 MHz ticks) taken at phase boundaries inside the single-workgroup kernels of the
- * last iteration: [0..15] octree build, [16..31] population */
+ * last iteration: [0..15] octree build, [16..31] population.  The kernels take the stamps only in the diagnostic variant
+ * library (-DPFT_DIAG); the product library returns zeros */
 int pft_debug_get_ticks(pft_tracker* t, uint64_t* ticks32);
 /* descent statistics of the last pft_eval_weights call that asked for the NN arrays: [0..10] queries by
  * number of generic levels, [11] queries that used the jump table, [12] wave iterations, [13..15] sums of

@@ -26,6 +26,19 @@
 #ifndef PFT_LIK_PENALTY
 #define PFT_LIK_PENALTY 1
 #endif
+// lanes that run along when a per-lane loop iteration has 8 or fewer active lanes (0: no padding)
+#ifndef PFT_LIK_PAD
+#define PFT_LIK_PAD 0
+#endif
+#ifndef PFT_LIK_PAD_FAST
+#define PFT_LIK_PAD_FAST PFT_LIK_PAD
+#endif
+#ifndef PFT_LIK_PAD_GEN
+#define PFT_LIK_PAD_GEN PFT_LIK_PAD
+#endif
+#ifndef PFT_LIK_PAD_LEAF
+#define PFT_LIK_PAD_LEAF PFT_LIK_PAD
+#endif
 
 struct LikCtx {
   const uint32_t* words;   // LDS or HBM
@@ -191,6 +204,41 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         }
         // fast levels: follow the key while the child containing the query exists (a divergent loop: a version
         // with a wave-uniform trip count and predicated steps was slower, 280 us against 267)
+#if PFT_LIK_PAD_FAST
+        {  // (as the generic loop below: an iteration with 8 or fewer lanes left is kept company by lanes 0 .. PFT_LIK_PAD-1)
+          auto fast_step = [&](uint32_t& nd, int& lv) -> bool {
+            const int sh = D - lv - 1;
+            const uint32_t c = (((kx >> sh) & 1u) << 2) | (((ky >> sh) & 1u) << 1) | ((kz >> sh) & 1u);
+            const uint32_t wv = W[nd];
+            if (!((wv >> c) & 1u)) return false;
+            nd = (wv >> 8) + __popc(wv & 0xffu & ((1u << c) - 1u));
+            lv++;
+            return true;
+          };
+          bool fa = lvl < lim;
+          for (;;) {
+            const unsigned long long am = __ballot(fa);
+            if (!am) break;
+            if (__popcll(am) > 8) {
+              if (fa) {
+                fa = fast_step(node, lvl);
+                if (fa) dbg_fast++;
+                fa = fa && lvl < lim;
+              }
+            } else if (fa || lane < PFT_LIK_PAD_FAST) {
+              uint32_t n2 = fa ? node : 0u;
+              int l2 = fa ? lvl : 0;
+              const bool go = fast_step(n2, l2);
+              if (fa) {
+                node = n2;
+                lvl = l2;
+                if (go) dbg_fast++;
+                fa = go && lvl < lim;
+              }
+            }
+          }
+        }
+#else
         while (lvl < lim) {
           const int sh = D - lvl - 1;
           const uint32_t c = (((kx >> sh) & 1u) << 2) | (((ky >> sh) & 1u) << 1) | ((kz >> sh) & 1u);
@@ -200,6 +248,7 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
           lvl++;
           dbg_fast++;
         }
+#endif
         const int up = D - lvl;
         const uint32_t top = 1u << lvl;
         jx = (kx >> up) | top; jy = (ky >> up) | top; jz = (kz >> up) | top;
@@ -209,7 +258,9 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         node = cx.leaf0;
         lvl = D;
       }
-      for (; lvl < D; lvl++) {
+      // One generic level on (node, jx, jy, jz), as a step so that the loop below can run it for lanes that only keep the
+      // wave company (PFT_LIK_PAD).
+      auto generic_step = [&](uint32_t& node, uint32_t& jx, uint32_t& jy, uint32_t& jz, const int lvl) {
         dbg_gen++;
         const uint32_t wv = W[node];
         const uint32_t mask = wv & 0xffu, base = wv >> 8;
@@ -279,7 +330,37 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         jx = 2u * jx + ((bc >> 2) & 1u);
         jy = 2u * jy + ((bc >> 1) & 1u);
         jz = 2u * jz + (bc & 1u);
+      };
+#if PFT_LIK_PAD_GEN
+      // gfx950 runs a wave64 compare / select / min / bit-field instruction in ~21 cycles instead of ~4 when 8 or fewer
+      // of its lanes are active (tools/micro/exec_mask_test.hip; plain adds are not affected), and the last iterations of
+      // this per-lane loop are exactly that: a couple of lanes with one level more to go than the rest.  Such an iteration
+      // is run with lanes 0 .. PFT_LIK_PAD-1 executing the step as well, on the root, results discarded.
+      for (;;) {
+        const bool act = lvl < D;
+        const unsigned long long am = __ballot(act);
+        if (!am) break;
+        if (__popcll(am) > 8) {  // (wave-uniform)
+          if (act) {
+            generic_step(node, jx, jy, jz, lvl);
+            lvl++;
+          }
+        } else if (act || lane < PFT_LIK_PAD_GEN) {
+          uint32_t n2 = act ? node : 0u, x2 = act ? jx : 1u, y2 = act ? jy : 1u, z2 = act ? jz : 1u;
+          const int g0 = dbg_gen, h0 = dbg_hard;
+          generic_step(n2, x2, y2, z2, act ? lvl : 0);
+          if (act) {
+            node = n2; jx = x2; jy = y2; jz = z2;
+            lvl++;
+          } else if (DEBUG_NN) {
+            dbg_gen = g0;
+            dbg_hard = h0;
+          }
+        }
       }
+#else
+      for (; lvl < D; lvl++) generic_step(node, jx, jy, jz, lvl);
+#endif
       // ---- leaf scan: first strictly-smaller wins (insertion order) ----
       uint32_t ls, le;
       if (LEAF == 1) {  // leaf starts as u16 in LDS (cropped clouds below 65536 points)
@@ -296,7 +377,7 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
       if (abl & 2) le = ls;
       float bd = (abl & 2) ? 1.0e-3f : INFINITY;
       uint32_t bpos = ls;
-      for (uint32_t pos = ls; pos < le; pos += 2) {  // two candidates per round: their gathers overlap
+      auto leaf_round = [&](const uint32_t pos, const uint32_t le, float& bd, uint32_t& bpos) {  // two candidates: their gathers overlap
         const bool two = pos + 1 < le;
         const float4 c = d.leaf_pts[pos];
         const float4 c2 = d.leaf_pts[two ? pos + 1 : pos];
@@ -310,7 +391,34 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         better = two & (dd < bd);
         bd = better ? dd : bd;
         bpos = better ? pos + 1 : bpos;
+      };
+#if PFT_LIK_PAD_LEAF
+      {  // (the second and later rounds belong to the few lanes whose leaf holds more than two points: padded as above)
+        uint32_t pos = ls;
+        for (;;) {
+          const bool act = pos < le;
+          const unsigned long long am = __ballot(act);
+          if (!am) break;
+          if (__popcll(am) > 8) {
+            if (act) {
+              leaf_round(pos, le, bd, bpos);
+              pos += 2;
+            }
+          } else if (act || lane < PFT_LIK_PAD_LEAF) {
+            float bd2 = bd;
+            uint32_t bp2 = bpos;
+            leaf_round(act ? pos : ls, act ? le : ls + 1u, bd2, bp2);  // (a leaf holds at least one point: ls is a valid record)
+            if (act) {
+              bd = bd2;
+              bpos = bp2;
+              pos += 2;
+            }
+          }
+        }
       }
+#else
+      for (uint32_t pos = ls; pos < le; pos += 2) leaf_round(pos, le, bd, bpos);
+#endif
       // the winner's record (position + packed colour) is fetched again instead of being carried through the loop
       const float4 bt = d.leaf_pts[bpos];
       if (DEBUG_NN) {

@@ -14,7 +14,15 @@
 // Output in HBM: words[], leaf_pts[], leaf_order[], jump[], header.
 #include "pft_device_utils.h"
 
+// Phase stamps (tools/phase_ticks.py) exist in the diagnostic variant only (-DPFT_DIAG): a wall_clock64() is an
+// s_memrealtime + s_waitcnt, and the thirty of them in a build sat on this one-workgroup kernel's critical path.
+#ifdef PFT_DIAG
 #define STAMP(k) do { if (threadIdx.x == 0) d.hdr->ticks[k] = wall_clock64(); } while (0)
+#define TICK_NOW() wall_clock64()
+#else
+#define STAMP(k) do { } while (0)
+#define TICK_NOW() 0ull
+#endif
 
 struct BuildSh {
   double mn[3], mx[3];
@@ -117,7 +125,9 @@ __device__ __forceinline__ void box_replay(BuildSh& S, const float4* __restrict_
     }
   };
   if (tid >= WAVE) local_aabb();
+#ifdef PFT_DIAG
   if (tid == WAVE) hdr_ticks[13] = wall_clock64();
+#endif
   if (tid < WAVE) {
     float4 q[PFT_REPLAY_HEAD / WAVE];
 #pragma unroll
@@ -184,7 +194,9 @@ __device__ __forceinline__ void box_replay(BuildSh& S, const float4* __restrict_
       S.err = err;
     }
     if (tid == 0) S.cur = head;
+#ifdef PFT_DIAG
     if (tid == 0) hdr_ticks[14] = wall_clock64();
+#endif
   }
   __syncthreads();
   if (S.err || n <= PFT_REPLAY_HEAD) return;
@@ -450,7 +462,7 @@ __device__ __forceinline__ bool build_tree(const PftParams& prm, const PftDev& d
   unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, t0_, t1_;
   for (int l = l0; l < D && !S.err; l++) {
     const int bit = D - 1 - l;
-    t0_ = wall_clock64();
+    t0_ = TICK_NOW();
     st.each(n, [&](uint32_t, key_t& key, uint32_t& node) {
       if (l > l0) {  // move to the level-l node chosen by the previous level's bits
         uint32_t w = W[node];
@@ -463,7 +475,7 @@ __device__ __forceinline__ bool build_tree(const PftParams& prm, const PftDev& d
       if (!(W[node] & cb)) atomicOr(&W[node], cb);
     });
     __syncthreads();
-    t1_ = wall_clock64(); tA += t1_ - t0_; t0_ = t1_;
+    t1_ = TICK_NOW(); tA += t1_ - t0_; t0_ = t1_;
     // child_base: each thread owns a contiguous run of this level's nodes, one workgroup scan per level
     // (two barriers: the scan scratch alternates between levels); the next level's words are zeroed in the
     // same phase as the bases are written
@@ -472,7 +484,7 @@ __device__ __forceinline__ bool build_tree(const PftParams& prm, const PftDev& d
     const uint32_t a0 = ls + min(nl, tid * per), a1 = ls + min(nl, (tid + 1) * per);
     uint32_t cnt = 0;
     for (uint32_t nd = a0; nd < a1; nd++) cnt += __popc(W[nd] & 0xffu);
-    t1_ = wall_clock64(); tB += t1_ - t0_; t0_ = t1_;
+    t1_ = TICK_NOW(); tB += t1_ - t0_; t0_ = t1_;
     uint32_t* scr = S.u32s + (l & 1) * 20;
     uint32_t inc = wave_incl_scan(cnt);
     if (lane_id() == WAVE - 1) scr[wave_id()] = inc;
@@ -485,7 +497,7 @@ __device__ __forceinline__ bool build_tree(const PftParams& prm, const PftDev& d
       if (lane_id() == nw - 1) scr[17] = ti;
     }
     __syncthreads();
-    t1_ = wall_clock64(); tC += t1_ - t0_; t0_ = t1_;
+    t1_ = TICK_NOW(); tC += t1_ - t0_; t0_ = t1_;
     uint32_t base = le + scr[wave_id()] + inc - cnt;
     const uint32_t nend = le + scr[17];
     const bool overflow = nend + 2 > d.max_words || nend >= (1u << 24);
@@ -502,10 +514,12 @@ __device__ __forceinline__ bool build_tree(const PftParams& prm, const PftDev& d
     }
     if (tid == 0) S.lvl[l + 2] = nend;
     __syncthreads();
-    t1_ = wall_clock64(); tD += t1_ - t0_;
+    t1_ = TICK_NOW(); tD += t1_ - t0_;
     if (S.err) break;
   }
+#ifdef PFT_DIAG
   if (tid == 0) { d.hdr->ticks[9] = tA; d.hdr->ticks[10] = tB; d.hdr->ticks[11] = tC; d.hdr->ticks[12] = tD; }
+#endif
   __syncthreads();
   if (S.err || D <= 0) {
     *out_leaf_start = 0;

@@ -32,7 +32,11 @@
 #ifndef PFT_POPC_POLL_SLEEP
 #define PFT_POPC_POLL_SLEEP 1  // s_sleep units (64 cycles) between two polls of a barrier counter
 #endif
+#ifdef PFT_DIAG  // phase stamps for tools/phase_ticks.py: diagnostic variant only (an s_memrealtime + wait each)
 #define STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) d.hdr->ticks[16 + (k)] = wall_clock64(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
 
 #define PFT_POPC_THREADS 256
 #define PFT_POPC_SPIN_LIMIT (1u << 22)

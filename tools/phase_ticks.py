@@ -1,5 +1,8 @@
 """Phase breakdown of the two single-workgroup kernels (octree build, population) from the in-kernel
-wall-clock stamps (100 MHz).  Usage on the GPU box:  python tools/phase_ticks.py [P] [N]"""
+wall-clock stamps (100 MHz).  The stamps are compiled into the diagnostic variant only (they cost several microseconds on
+the one-workgroup kernels' critical path):
+    python tools/build_variant.py diag -DPFT_DIAG                              (here)
+    PFT_LIB_PATH=$PWD/pcl_tracking_amd/_build/var_diag.so python tools/phase_ticks.py [P] [N]     (GPU box)"""
 import ctypes as C
 import os
 import sys

@@ -287,3 +287,24 @@ if __name__ == "__main__":
     mx = wg.max(2)
     print("lanes attaining the wave max: mean %.1f; rounds where <=4 lanes attain it: %.3f, <=8: %.3f, <=16: %.3f" % (
         (wg == mx[..., None]).sum(2).mean(), ((wg == mx[..., None]).sum(2) <= 4).mean(), ((wg == mx[..., None]).sum(2) <= 8).mean(), ((wg == mx[..., None]).sum(2) <= 16).mean()))
+
+
+def low_lane_iterations(X, step=1):
+    """iterations of a per-lane loop (trip count X per lane, `step` units per iteration) per 64-query round, and how many of
+    them run with 1..8 active lanes (tools/micro/exec_mask_test.hip: such instructions cost 4-5 x on gfx950)"""
+    W = X.reshape(X.shape[0], -1, 64)
+    tot = low = 0
+    for t in range(0, int(W.max()) + step, step):
+        act = (W > t).sum(2)
+        tot += (act > 0).sum()
+        low += ((act > 0) & (act <= 8)).sum()
+    n = W.shape[0] * W.shape[1]
+    return tot / n, low / n
+
+
+if __name__ == "__main__":
+    for name, X, step in (("generic levels", G, 1), ("fast levels", F, 1), ("leaf rounds (2 candidates)", LS, 2)):
+        tot, low = low_lane_iterations(X, step)
+        print("%-28s iterations per round %.2f, of which with <= 8 active lanes %.2f" % (name, tot, low))
+    print("coherence (gate) lanes active per round: mean %.1f; rounds with 1..8 lanes: %.3f" % (
+        GATE.reshape(GATE.shape[0], -1, 64).sum(2).mean(), ((GATE.reshape(GATE.shape[0], -1, 64).sum(2) <= 8) & (GATE.reshape(GATE.shape[0], -1, 64).sum(2) > 0)).mean()))
