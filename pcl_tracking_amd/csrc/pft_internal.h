@@ -91,6 +91,7 @@ struct PftHeader {  // lives in HBM; written by kernels, read by later kernels (
   uint32_t lvl_start[PFT_MAX_DEPTH + 3];
   int32_t n_grow;
   int32_t build_path;   // 1 = register/LDS-resident builder, 0 = generic builder (diagnostic)
+  int32_t leaf_indirect;  // 1: leaf_pts was NOT written for this tree; the likelihood kernel reads crop_pts[leaf_order[pos]]
   // fast descent (pft_likelihood.hip): direct-index table of the level-J nodes and the safety margin
   int32_t jump_level;   // J (0 = no table): jump[kx | ky<<J | kz<<2J] = 1 + index of the node inside level J
   float margin_cells;   // a query closer than this (in leaf cells) to a cell face takes the exact generic step
@@ -219,7 +220,7 @@ void pftk_resample_kld(hipStream_t s, const PftParams& p, const PftDev& d, uint3
 // raw: the input in PCL's 32-byte layout when its 16-byte records have not been formed yet (first crop of a frame), else null
 void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d, bool bbox_from_partials, uint32_t epoch,
                const pft_point_xyzrgba* raw);
-void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t expected_points);
+void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t expected_points, bool allow_indirect = true);
 // no-op launch unless the sorted builder flagged "radix passes too few" (error bit 3): then the single-workgroup build
 void pftk_octree_rescue(hipStream_t s, const PftParams& p, const PftDev& d);
 struct SortBufs {

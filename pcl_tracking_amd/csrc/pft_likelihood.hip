@@ -99,6 +99,7 @@ template <bool USE_TAB, bool FAST, bool DEBUG_NN, int LEAF, typename WordPtr>
 __device__ __forceinline__ void likelihood_items(const PftParams& prm, const PftDev& d, const LikCtx& cx, WordPtr W,
                                                  uint32_t n_particles, int D, uint32_t n_crop,
                                                  const double omin[3], int abl) {
+  const bool indirect = d.hdr->leaf_indirect != 0;  // (wave-uniform)
   const int lane = lane_id(), w = wave_id(), nw = blockDim.x >> 6;
   const uint32_t M = prm.M, nchunk = prm.nchunk;
   // Work distribution.  The cost of an item depends on where its queries land, and with a static round-robin the
@@ -377,20 +378,29 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
       if (abl & 2) le = ls;
       float bd = (abl & 2) ? 1.0e-3f : INFINITY;
       uint32_t bpos = ls;
+      // `indirect` (wave-uniform, PftHeader::leaf_indirect): the builder left the point records where the crop put them,
+      // a candidate is crop_pts[leaf_order[pos]]; bpos then carries the record's index in crop_pts
       auto leaf_round = [&](const uint32_t pos, const uint32_t le, float& bd, uint32_t& bpos) {  // two candidates: their gathers overlap
         const bool two = pos + 1 < le;
-        const float4 c = d.leaf_pts[pos];
-        const float4 c2 = d.leaf_pts[two ? pos + 1 : pos];
+        uint32_t i1 = pos, i2 = two ? pos + 1 : pos;
+        const float4* __restrict__ rec = d.leaf_pts;
+        if (indirect) {
+          i1 = d.leaf_order[i1];
+          i2 = d.leaf_order[i2];
+          rec = d.crop_pts;
+        }
+        const float4 c = rec[i1];
+        const float4 c2 = rec[i2];
         float dx = c.x - qx, dy = c.y - qy, dz = c.z - qz;
         float dd = dx * dx + (dy * dy + dz * dz);
         bool better = dd < bd;
         bd = better ? dd : bd;
-        bpos = better ? pos : bpos;
+        bpos = better ? i1 : bpos;
         dx = c2.x - qx; dy = c2.y - qy; dz = c2.z - qz;
         dd = dx * dx + (dy * dy + dz * dz);
         better = two & (dd < bd);
         bd = better ? dd : bd;
-        bpos = better ? pos + 1 : bpos;
+        bpos = better ? i2 : bpos;
       };
 #if PFT_LIK_PAD_LEAF
       {  // (the second and later rounds belong to the few lanes whose leaf holds more than two points: padded as above)
@@ -420,10 +430,13 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
       for (uint32_t pos = ls; pos < le; pos += 2) leaf_round(pos, le, bd, bpos);
 #endif
       // the winner's record (position + packed colour) is fetched again instead of being carried through the loop
-      const float4 bt = d.leaf_pts[bpos];
+      // (no candidate beat +inf -- a NaN query --: bpos still holds the leaf position it started from; the direct path
+      // reports the leaf's first record then, and so does this one)
+      if (indirect && !(bd < INFINITY)) bpos = d.leaf_order[min(bpos, n_crop - 1u)];
+      const float4 bt = indirect ? d.crop_pts[bpos] : d.leaf_pts[bpos];
       if (DEBUG_NN) {
         const size_t o = (size_t)pi * M + d.ref_perm[j];
-        d.nn_idx[o] = (int32_t)d.leaf_order[bpos];
+        d.nn_idx[o] = indirect ? (int32_t)bpos : (int32_t)d.leaf_order[bpos];
         d.nn_d2[o] = bd;
         st_q += 1;
         st_s += le - ls;

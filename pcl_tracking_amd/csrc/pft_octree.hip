@@ -660,7 +660,7 @@ __global__ __launch_bounds__(PFT_BUILD_THREADS) void k_octree_build(PftParams pr
   STAMP(7);
   const int D = S.depth;
   const bool ok = n > 0 && !S.err && D > 0;
-  if (copy_leaf_pts && ok) {  // small crops: the leaf-ordered point records are copied here instead of by k_leaf_gather
+  if (copy_leaf_pts == 1 && ok) {  // small crops: the leaf-ordered point records are copied here instead of by k_leaf_gather
     __threadfence_block();    // (a launch costs more than moving a few thousand records through one CU)
     for (uint32_t pos = tid; pos < n; pos += blockDim.x) d.leaf_pts[pos] = d.crop_pts[d.leaf_order[pos]];
   }
@@ -676,6 +676,7 @@ __global__ __launch_bounds__(PFT_BUILD_THREADS) void k_octree_build(PftParams pr
     hdr->use_table = use_table;
     hdr->n_grow = S.ngrow;
     hdr->build_path = path;
+    hdr->leaf_indirect = copy_leaf_pts == 2 ? 1 : 0;  // 2: nobody copies the records, the likelihood kernel follows leaf_order
     if (d.host_stat) d.host_stat[1] = (uint32_t)D;
     hdr->jump_level = (ok && use_table) ? S.jump : 0;
     hdr->n_leaves = ok ? n_leaves : 0;
@@ -721,15 +722,23 @@ static void pftk_octree_set_attr() {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
 }
 
-void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t expected_points) {
+void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t expected_points, bool allow_indirect) {
   // static LDS of the kernel (BuildSh ~2.6 KB, the dense top-level arrays 5 KB): leave 10 KB out of the dynamic request
   const uint32_t lds = ((uint32_t)pftk_max_lds_bytes() - 10240u) & ~15u;
   pftk_octree_set_attr();
-  // the crop size of the previous iteration decides who copies the leaf records (either way is correct for any size)
-  const int copy_in_kernel = expected_points <= 5000u ? 1 : 0;
-  hipLaunchKernelGGL(k_octree_build, dim3(1), dim3(PFT_BUILD_THREADS), lds, s, p, d, lds, copy_in_kernel, 0);
+  // Who produces the leaf-ordered point records (any choice is correct for any size; the builder records it in the header):
+  //   2  nobody: the likelihood kernel reads crop_pts[leaf_order[pos]] -- one more dependent 4-byte load per candidate
+  //      (measured +0.32 ps per query: 5.4 us per launch at 8 192 particles x 2 048 points) against a launch of its own
+  //      (4.6 us) or scattered stores by the one builder workgroup; the caller allows it when the launch is small
+  //      (allow_indirect); PFT_LEAF_INDIRECT=0 keeps the copies, =1 forces the indirection (A/B timing, cross-check)
+  //   1  the builder itself (crops of at most 5 000 points, by the previous iteration's size)
+  //   0  k_leaf_gather, a launch of many workgroups
+  const char* e = getenv("PFT_LEAF_INDIRECT");
+  const bool indirect = e ? e[0] == '1' : allow_indirect;
+  const int mode = indirect ? 2 : (expected_points <= 5000u ? 1 : 0);
+  hipLaunchKernelGGL(k_octree_build, dim3(1), dim3(PFT_BUILD_THREADS), lds, s, p, d, lds, mode, 0);
   // at most PFT_SORTED_BUILD_MIN-ish points reach this builder in practice, but any crop (<= N) is legal
-  if (!copy_in_kernel)
+  if (mode == 0)
     hipLaunchKernelGGL(k_leaf_gather, dim3((d.N + 255u) / 256u ? (d.N + 255u) / 256u : 1u), dim3(256), 0, s, d);
 }
 

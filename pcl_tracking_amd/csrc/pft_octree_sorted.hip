@@ -181,6 +181,7 @@ __global__ __launch_bounds__(1024) void k_so_replay(PftParams prm, PftDev d, con
     hdr->use_table = use_table;
     hdr->n_grow = S.ngrow;
     hdr->build_path = 2;
+    hdr->leaf_indirect = 0;  // this builder writes leaf_pts itself
     hdr->jump_level = (ok && use_table) ? J : 0;
     double maxabs = 0.0;
     for (int a = 0; a < 3; a++) maxabs = fmax(maxabs, fmax(fabs(S.mn[a]), fabs(S.mx[a])));

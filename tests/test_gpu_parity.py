@@ -980,3 +980,32 @@ def test_fused_resample_box_equals_the_separate_launches(gpu, data, kind, monkey
             assert p0.tobytes() == p1.tobytes()
             assert r0.tobytes() == r1.tobytes()
             assert len(i0) > 100
+
+
+@pytest.mark.parametrize("P", [512, 8192])
+def test_leaf_records_copied_or_followed_give_the_same_bits(gpu, data, P, monkeypatch):
+    """Round 3: for small launches the single-workgroup builder leaves the point records where the crop put them and the
+    likelihood kernel reads crop_pts[leaf_order[pos]] (PftHeader::leaf_indirect; default below ~8 million queries);
+    PFT_LEAF_INDIRECT=0 / 1 force the copied / the followed form.  Same neighbours, same distances, same frames."""
+    runs = []
+    for env in ("0", "1"):
+        monkeypatch.setenv("PFT_LEAF_INDIRECT", env)
+        t = gpu.make_reference_tracker(particle_num=P, seed=5)
+        t.setReferenceCloud(data["model"])
+        t.setTrans(scene.initial_trans())
+        t.setInputCloud(data["scene"])
+        frames = []
+        for _ in range(3):
+            t.compute()
+            t.synchronize()
+            frames.append((t.getParticles().copy(), t.getResult().copy()))
+        ev = t.evalWeights(t.getParticles()[:64], want_nn=True)
+        runs.append((frames, ev))
+    monkeypatch.delenv("PFT_LEAF_INDIRECT")
+    (f0, e0), (f1, e1) = runs
+    for (p0, r0), (p1, r1) in zip(f0, f1):
+        assert p0.tobytes() == p1.tobytes() and r0.tobytes() == r1.tobytes()
+    np.testing.assert_array_equal(e0["nn_idx"], e1["nn_idx"])
+    np.testing.assert_array_equal(e0["nn_d2"].view(np.uint32), e1["nn_d2"].view(np.uint32))
+    np.testing.assert_array_equal(e0["raw"].view(np.uint32), e1["raw"].view(np.uint32))
+    assert (e0["nn_idx"] >= 0).all()
