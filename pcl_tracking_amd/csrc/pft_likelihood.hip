@@ -648,8 +648,11 @@ __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * 
     const uint32_t* W = lwords;
     if (fast)
       likelihood_items<true, true, DEBUG_NN, 2>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
-    else
+    else if (use_tab)
       likelihood_items<true, false, DEBUG_NN, 2>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+    else  // trees deeper than PFT_TABLE_MAX_DEPTH have no centre tables (found by tools/fuzz_parity.py: this layout used to
+          // read them regardless -- a 12-level tree over a 41 m crop box sent every query to one leaf)
+      likelihood_items<false, false, DEBUG_NN, 2>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
   } else if (words_in_lds && leaf16) {  // node words addressed as LDS (ds_read), not through a generic pointer
     const uint32_t* W = lwords;
     if (fast)
@@ -717,9 +720,12 @@ void pftk_likelihood(hipStream_t s, const PftParams& p, const PftDev& d, uint32_
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set[dev] = e1 == hipSuccess && e2 == hipSuccess;
   }
-  if (g_allow_fast < 0) {  // PFT_GENERIC_DESCENT=1: all-generic descent (A/B and parity cross-check)
+  {  // PFT_GENERIC_DESCENT=1: all-generic descent (A/B and parity cross-check; read per launch: tools/fuzz_parity.py draws it per case)
     const char* e = getenv("PFT_GENERIC_DESCENT");
-    g_allow_fast = (e && e[0] == '1') ? 0 : 1;
+    if (g_allow_fast < 0) g_allow_fast = 1;
+    g_allow_fast = (g_allow_fast & ~1) | ((e && e[0] == '1') ? 0 : 1);
+  }
+  {
 #ifdef PFT_DIAG
     const char* a = getenv("PFT_ABLATE");  // timing experiments only: bit0 generic levels, bit1 leaf scan, bit2 coherence
     if (a) g_allow_fast |= atoi(a) << 8;

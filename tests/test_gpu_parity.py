@@ -1009,3 +1009,24 @@ def test_leaf_records_copied_or_followed_give_the_same_bits(gpu, data, P, monkey
     np.testing.assert_array_equal(e0["nn_d2"].view(np.uint32), e1["nn_d2"].view(np.uint32))
     np.testing.assert_array_equal(e0["raw"].view(np.uint32), e1["raw"].view(np.uint32))
     assert (e0["nn_idx"] >= 0).all()
+
+
+def test_deep_tree_without_centre_tables_in_the_branch_only_layout(gpu, orc):
+    """Found by tools/fuzz_parity.py (round 3): wild particles (0.5 m / 1 rad spread) give a crop box of tens of metres, the
+    octree gets 12 levels (> PFT_TABLE_MAX_DEPTH: no centre tables, all-generic descent), and with ~20 000 cropped points
+    the likelihood kernel keeps the branch levels in LDS and the leaf starts in L2 -- a layout whose dispatch used to take
+    the table-reading descent regardless, sending every query to one leaf."""
+    model = scene.make_model(65, seed=65)
+    cloud = scene.make_scene(20000)
+    g, o = make_pair(gpu, orc, model, cloud, 700)
+    p = particles_around(scene.model_gt_pose(), 700, 12345, 0.5, 1.0)
+    mats = g.debugPoseToMatrix(p)
+    G = g.evalWeights(p, want_nn=True)
+    O = o.eval_weights(p, want_nn=True, mats=mats)
+    assert O["octree_depth"] >= 11 and len(O["crop_idx"]) > 15000, (O["octree_depth"], len(O["crop_idx"]))
+    assert G["octree_depth"] == O["octree_depth"]
+    np.testing.assert_array_equal(G["crop_idx"], O["crop_idx"])
+    np.testing.assert_array_equal(G["nn_idx"], O["nn_idx"])
+    np.testing.assert_array_equal(G["nn_d2"].view(np.uint32), O["nn_d2"].view(np.uint32))
+    assert ulp_diff(G["raw"], O["raw"]).max() <= 1
+    assert len(np.unique(G["nn_idx"])) > 1000

@@ -1,0 +1,233 @@
+"""Randomised parity campaign on the GPU box: the HIP path through the C ABI against the CPU oracle on generated cases,
+for a time budget.  Two kinds of case:
+
+  eval   one weight evaluation (crop -> octree -> approximate nearest neighbour -> coherence) of random particles on a
+         random (model, cloud) pair: bounding box, crop list, octree depth / box / per-point keys / leaf count, the
+         neighbour index and squared distance of EVERY (particle, reference point) pair must be bit-equal, the raw
+         weights within 1 ulp (tests/test_gpu_parity.py::check_eval); builder (single workgroup / sorted), leaf-record
+         form (copied / followed) and descent (fast / all-generic) are drawn at random per case
+  track  2 - 6 frames of a whole tracker (fixed or KLD-adaptive, 1 - 3 iterations per frame) against the oracle in its
+         device-arithmetic modes: result pose, every particle, every weight bit-identical (tests/test_gpu_longrun.py)
+
+Clouds: the ray-cast scene (voxel / organised, several sizes), uniform cubes, clusters with duplicates, planes, clouds
+far from the origin, tiny extents, NaN / Inf contamination; models of 1 ... 3 000 points; particle sets from a single
+particle to a few thousand, tight and wild, some far outside the cloud (empty crops).
+
+    python tools/fuzz_parity.py [minutes] [seed]        (GPU box; prints a line per 25 cases, a summary at the end)
+A failing case prints its seed and parameters and the campaign goes on; exit code 1 if any case failed."""
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle as orc  # noqa: E402
+from pcl_tracking_amd import scene, tracker  # noqa: E402
+import test_gpu_parity as TP  # noqa: E402
+
+KEYS = ("x", "y", "z", "roll", "pitch", "yaw")
+minutes = float(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1] != "--case" else 10.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[1] != "--case" else 1
+_scene_cache = {}
+LAST = {}  # description of the case being run (printed when it fails)
+
+
+def cached_scene(kind, n):
+    if (kind, n) not in _scene_cache:
+        _scene_cache[(kind, n)] = scene.make_scene(n, mode="organized" if kind == "organized" else "voxel")
+    return _scene_cache[(kind, n)]
+
+
+def random_cloud(rng):
+    kind = rng.choice(["voxel", "voxel", "organized", "cube", "clusters", "plane", "far", "tiny", "nan"])
+    gt = np.array(scene.model_gt_pose()[:3])
+    if kind == "voxel":
+        c = cached_scene("voxel", int(rng.choice([3000, 20000, 50000])))
+    elif kind == "organized":
+        w = int(rng.choice([80, 160, 320]))
+        c = cached_scene("organized", w * (w * 3 // 4))
+    else:
+        n = int(rng.integers(1, 30000))
+        c = np.zeros(n, scene.POINT_DTYPE)
+        c["w"] = 1.0
+        c["rgba"] = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+        if kind == "cube":
+            xyz = gt + rng.uniform(-0.4, 0.4, (n, 3))
+        elif kind == "clusters":
+            cen = gt + rng.uniform(-0.3, 0.3, (max(1, n // 50), 3))
+            xyz = cen[rng.integers(0, len(cen), n)] + rng.normal(0, 0.004, (n, 3)) * (rng.random((n, 1)) < 0.7)
+        elif kind == "plane":
+            xyz = gt + rng.uniform(-0.3, 0.3, (n, 3))
+            xyz[:, int(rng.integers(0, 3))] = gt[0] + 0.05
+        elif kind == "far":
+            off = rng.uniform(-40, 40, 3)
+            xyz = gt + off + rng.uniform(-0.3, 0.3, (n, 3))
+        elif kind == "tiny":
+            xyz = gt + rng.uniform(-0.004, 0.004, (n, 3))
+        else:  # nan: a cube with non-finite coordinates mixed in (PCL's PassThrough drops them)
+            xyz = gt + rng.uniform(-0.3, 0.3, (n, 3))
+            bad = rng.random(n) < 0.05
+            xyz[bad, int(rng.integers(0, 3))] = rng.choice([np.nan, np.inf, -np.inf])
+        xyz = xyz.astype(np.float32)
+        c["x"], c["y"], c["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    return kind, c
+
+
+def random_model(rng):
+    M = int(rng.choice([1, 7, 63, 64, 65, 200, 513, 1024, 2048, 3000]))
+    return scene.make_model(M, seed=int(rng.integers(1, 1000)))
+
+
+def cloud_centre(cloud, kind):
+    if kind == "far":
+        ok = np.isfinite(cloud["x"]) & np.isfinite(cloud["y"]) & np.isfinite(cloud["z"])
+        return np.array([cloud["x"][ok].mean(), cloud["y"][ok].mean(), cloud["z"][ok].mean()])
+    return np.array(scene.model_gt_pose()[:3])
+
+
+def eval_case(rng, env):
+    kind, cloud = random_cloud(rng)
+    model = random_model(rng)
+    P = int(rng.choice([1, 2, 33, 64, 100, 257, 700]))
+    while P * len(model) > 600000:
+        P = max(1, P // 2)
+    c = cloud_centre(cloud, kind)
+    pose = (c[0], c[1], c[2]) + tuple(rng.uniform(-3.1, 3.1, 3) if rng.random() < 0.3 else scene.model_gt_pose()[3:])
+    sig_t = float(rng.choice([0.0, 0.005, 0.015, 0.1, 0.5]))
+    sig_r = float(rng.choice([0.0, 0.05, 0.09, 1.0]))
+    if rng.random() < 0.05:  # far outside the cloud: empty crop
+        pose = (pose[0] + 30.0,) + pose[1:]
+    desc = dict(kind=kind, N=len(cloud), M=len(model), P=P, sig_t=sig_t, sig_r=sig_r, pose=[round(float(v), 4) for v in pose], env=dict(env))
+    LAST.clear()
+    LAST.update(desc)
+    g, o = TP.make_pair(tracker, orc, model, cloud, P)
+    p = TP.particles_around(pose, P, int(rng.integers(1, 1 << 30)), sig_t, sig_r)
+    mats = g.debugPoseToMatrix(p)
+    G = g.evalWeights(p, want_nn=True)
+    O = o.eval_weights(p, want_nn=True, mats=mats)
+    LAST.update(crop=len(O["crop_idx"]), depth_dev=int(G["octree_depth"]), depth_orc=int(O["octree_depth"]), leaves_dev=int(G["n_leaves"]),
+                omin=[float(v) for v in O["octree_min"]], omax=[float(v) for v in O["octree_max"]])
+    np.testing.assert_array_equal(G["bbox"], O["bbox"].astype(np.float32))
+    np.testing.assert_array_equal(G["crop_idx"], O["crop_idx"])
+    if len(O["crop_idx"]) == 0:
+        assert (G["raw"] == 0).all() and (O["raw"] == 0).all() and (G["nn_idx"] == -1).all()
+        return desc, "empty"
+    assert G["octree_depth"] == O["octree_depth"], (G["octree_depth"], O["octree_depth"])
+    np.testing.assert_array_equal(G["octree_min"], O["octree_min"])
+    np.testing.assert_array_equal(G["octree_max"], O["octree_max"])
+    ot = orc.Octree(np.ascontiguousarray(cloud)[O["crop_idx"]])
+    if len(O["crop_idx"]) <= 20000:  # (orc_octree_point_key is a Python-side loop)
+        np.testing.assert_array_equal(G["point_keys"], ot.point_keys())
+    assert G["n_leaves"] == ot.info()["leaves"]
+    np.testing.assert_array_equal(G["nn_idx"], O["nn_idx"])
+    np.testing.assert_array_equal(G["nn_d2"].view(np.uint32), O["nn_d2"].view(np.uint32))
+    assert G["scan_queries"] == O["scan_queries"] and G["scan_points"] == O["scan_points"]
+    d = TP.ulp_diff(G["raw"], O["raw"])
+    assert d.max() <= 1, d.max()
+    return desc, "depth %d crop %d" % (G["octree_depth"], len(G["crop_idx"]))
+
+
+def track_case(rng, env):
+    kld = bool(rng.random() < 0.35)
+    P = int(rng.choice([300, 400, 500])) if kld else int(rng.choice([1, 64, 400, 1000, 3000]))
+    iters = int(rng.integers(1, 4))
+    frames = int(rng.integers(2, 7))
+    seed = int(rng.integers(1, 1 << 30))
+    M = int(rng.choice([200, 1024, 2048]))
+    model = scene.make_model(M)
+    desc = dict(kld=kld, P=P, iters=iters, frames=frames, seed=seed, M=M, env=dict(env))
+    LAST.clear()
+    LAST.update(desc)
+    g = tracker.make_reference_tracker(particle_num=P, seed=seed, kld=kld)
+    g.setIterationNum(iters)
+    o = orc.Tracker(orc.default_config(particle_num=P, seed=seed, threads=0, emulate_pcl_alloc=0, iteration_num=iters,
+                                       kld_adaptive=1 if kld else 0))
+    o.set_trig_mode(1)
+    o.set_sum_mode(1)
+    for ref, tr in ((g.setReferenceCloud, g.setTrans), (o.set_reference, o.set_trans)):
+        ref(model)
+        tr(scene.initial_trans())
+    for f in range(frames):
+        kind = rng.choice(["voxel", "organized"])
+        if kind == "voxel":
+            cloud = cached_scene("voxel", int(rng.choice([3000, 20000, 50000])))
+        else:
+            w = int(rng.choice([80, 160, 320]))
+            cloud = cached_scene("organized", w * (w * 3 // 4))
+        g.setInputCloud(cloud)
+        o.set_input(cloud)
+        g.compute()
+        assert o.compute() == 0
+        rg, ro = g.getResult(), o.get_result()
+        assert rg.tobytes() == ro.tobytes(), (f, rg, ro)
+        pg, po = g.getParticles(), o.get_particles()
+        assert len(pg) == len(po), (f, len(pg), len(po))
+        for k in KEYS + ("weight",):
+            np.testing.assert_array_equal(pg[k].view(np.uint32), po[k].view(np.uint32), err_msg="frame %d field %s" % (f, k))
+    return desc, "ok"
+
+
+def run_case(cseed):
+    crng = np.random.default_rng(cseed)
+    env = {}
+    b = crng.choice(["", "single", "sorted"])
+    if b:
+        env["PFT_FORCE_BUILDER"] = str(b)
+    li = crng.choice(["", "0", "1"])
+    if li:
+        env["PFT_LEAF_INDIRECT"] = str(li)
+    if crng.random() < 0.15:
+        env["PFT_GENERIC_DESCENT"] = "1"
+    for k in ("PFT_FORCE_BUILDER", "PFT_LEAF_INDIRECT", "PFT_GENERIC_DESCENT"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    for k, v in os.environ.items():  # (repro runs: overrides given on the command line as FUZZ_<NAME>=value)
+        if k.startswith("FUZZ_"):
+            os.environ[k[5:]] = v
+            env[k[5:]] = v
+    kind = "track" if crng.random() < 0.25 else "eval"
+    return kind, env, (track_case if kind == "track" else eval_case)(crng, env)
+
+
+def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--case":  # python tools/fuzz_parity.py --case SEED: one case, verbosely
+        try:
+            print(run_case(int(sys.argv[2])))
+        finally:
+            print("case:", LAST)
+        return 0
+    rng = np.random.default_rng(seed0)
+    t_end = time.time() + minutes * 60.0
+    n = {"eval": 0, "track": 0}
+    failed = []
+    notes = {}
+    t0 = time.time()
+    case = 0
+    while time.time() < t_end:
+        case += 1
+        cseed = int(rng.integers(1, 1 << 62))
+        kind, env = "?", {}
+        try:
+            kind, env, (desc, note) = run_case(cseed)
+            n[kind] += 1
+            notes[note.split(" ")[0]] = notes.get(note.split(" ")[0], 0) + 1
+        except Exception as e:  # noqa: BLE001  (the campaign goes on; the case is reported with its seed)
+            failed.append((kind, cseed, repr(e)[:300]))
+            print("FAILED %s case seed %d env %s: %s\n   case: %s" % (kind, cseed, env, repr(e)[:500], LAST), flush=True)
+            traceback.print_exc(limit=2)
+        if case % 25 == 0:
+            print("%5d cases in %.0f s (eval %d, track %d), failures %d" % (case, time.time() - t0, n["eval"], n["track"], len(failed)), flush=True)
+    print("campaign seed %d: %d eval cases, %d track cases in %.1f min; outcomes %s; FAILURES: %d" % (
+        seed0, n["eval"], n["track"], (time.time() - t0) / 60.0, notes, len(failed)))
+    for f in failed:
+        print("   ", f)
+    return 1 if failed else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
