@@ -6,6 +6,11 @@ for a time budget.  Two kinds of case:
          neighbour index and squared distance of EVERY (particle, reference point) pair must be bit-equal, the raw
          weights within 1 ulp (tests/test_gpu_parity.py::check_eval); builder (single workgroup / sorted), leaf-record
          form (copied / followed) and descent (fast / all-generic) are drawn at random per case
+  filter the input front end (PassThrough + ApproximateVoxelGrid fused, VoxelGrid) on random clouds, leaf sizes, history
+         sizes and limits: output bytes, counts and pass indices are the oracle's
+  exact  NearestPairPointCloudCoherence mode against the oracle's exhaustive search, all three search paths
+  shard  the particle-sharded phases with 2 / 3 / 4 / 8 ranks as handles of one process, exchange steps done by hand:
+         every rank reproduces the single handle bit for bit
   track  2 - 6 frames of a whole tracker (fixed or KLD-adaptive, 1 - 3 iterations per frame) against the oracle in its
          device-arithmetic modes: result pose, every particle, every weight bit-identical (tests/test_gpu_longrun.py)
 
@@ -27,7 +32,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle as orc  # noqa: E402
-from pcl_tracking_amd import scene, tracker  # noqa: E402
+from pcl_tracking_amd import filters, scene, tracker  # noqa: E402
 import test_gpu_parity as TP  # noqa: E402
 
 KEYS = ("x", "y", "z", "roll", "pitch", "yaw")
@@ -172,6 +177,175 @@ def track_case(rng, env):
     return desc, "ok"
 
 
+def filter_case(rng, env):
+    """the input front end (include/pft_filters.h): PassThrough + ApproximateVoxelGrid fused, ApproximateVoxelGrid and
+    VoxelGrid alone, on a random cloud with random leaf sizes / history sizes / limits: the output bytes are the oracle's"""
+    n = int(rng.choice([0, 1, 2, 63, 1023, 1024, 1025, 4097, 20000, 70001, 150000]))
+    kind = rng.choice(["uniform", "runs", "frame", "nan", "negative"])
+    c = np.zeros(n, scene.POINT_DTYPE)
+    c["w"] = 1.0
+    c["rgba"] = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    span = float(rng.choice([0.004, 0.05, 0.3, 2.0]))
+    if kind == "frame" and n > 0:
+        w = int(rng.choice([120, 240, 480]))
+        c = scene.make_depth_frame(w, w * 9 // 16, seed=int(rng.integers(1, 1000)))
+        n = len(c)
+    elif kind == "runs" and n > 0:  # long runs of one voxel, few voxels: table entries collide and flush each other
+        lens = rng.choice([1, 2, 3, 7, 60, 255, 256, 257, 700, 1024, 2500], max(1, n // 200))
+        vox = rng.integers(0, 40, (len(lens), 3))
+        cell = np.repeat(vox, lens, axis=0)[:n]
+        c = c[: len(cell)]
+        n = len(c)
+        jit = rng.uniform(0.05, 0.95, (n, 3))
+        for a, k in enumerate(("x", "y", "z")):
+            c[k] = ((cell[:, a] + jit[:, a]) * 0.01).astype(np.float32)
+    else:
+        for k in ("x", "y", "z"):
+            c[k] = rng.uniform(-span, span, n).astype(np.float32)
+        if kind != "negative":
+            c["z"] += np.float32(1.0)
+        if kind == "nan" and n > 0:
+            bad = rng.random(n) < 0.08
+            for k in ("x", "y", "z"):
+                c[k][bad] = np.nan
+    leaf = tuple(float(v) for v in rng.choice([0.005, 0.01, 0.02, 0.05, 0.1], 3)) if rng.random() < 0.3 else (0.01, 0.01, 0.01)
+    hist = int(rng.choice([64, 512, 512, 1024, 2048]))
+    LAST.clear()
+    LAST.update(dict(filter=str(kind), n=n, leaf=leaf, hist=hist, span=span))
+    # the reference's fused front end
+    lo, hi = (0.0, 10.0) if rng.random() < 0.6 else (float(rng.uniform(-1, 1)), float(rng.uniform(1, 3)))
+    f = filters.make_reference_input_filter()
+    f.setPassThrough("z", lo, hi)
+    f.setLeafSize(*leaf)
+    f.setHistorySize(hist)
+    f.setInputCloud(c)
+    got = f.filter()
+    idx = orc.pass_through(c, "z", lo, hi)
+    want = orc.approx_voxel_grid(c[idx], leaf, hist)
+    assert f.counts() == (len(idx), len(want)), (f.counts(), len(idx), len(want))
+    np.testing.assert_array_equal(f.passIndices(), idx)
+    assert got.tobytes() == want.tobytes()
+    # VoxelGrid (exact) on the finite points
+    if n <= 80000:
+        g = filters.VoxelGrid()
+        g.setLeafSize(*leaf)
+        fin = c[idx] if kind in ("nan", "frame") else c
+        g.setInputCloud(fin)
+        gv, wv = g.filter(), orc.voxel_grid(fin, leaf)
+        if wv is None:  # PCL: "Leaf size is too small for the input dataset" -> the input is handed through unchanged
+            wv = fin
+        assert gv.tobytes() == wv.tobytes(), (len(gv), len(wv))
+    return dict(LAST), "filter"
+
+
+def shard_case(rng, env):
+    """the particle-sharded phases (pft_dist_*): W ranks as W handles of this one process, the two exchange steps done by
+    hand (element-wise max of the bbox6 buffers, concatenation of the shards = what all-reduce(MAX) and all-gather
+    deliver): every rank reproduces the single handle bit for bit, whatever W"""
+    import torch
+
+    from pcl_tracking_amd.dist import HipPhases
+
+    world = int(rng.choice([2, 3, 4, 8]))
+    P = world * int(rng.choice([1, 50, 128, 500, 1024]))
+    frames = int(rng.integers(1, 4))
+    iters = int(rng.integers(1, 4))
+    seed = int(rng.integers(1, 1 << 30))
+    M = int(rng.choice([200, 1024, 2048]))
+    LAST.clear()
+    LAST.update(dict(shard=True, world=world, P=P, frames=frames, iters=iters, seed=seed, M=M, env=dict(env)))
+    model = scene.make_model(M)
+    dev = torch.device("cuda", 0)
+    single = tracker.make_reference_tracker(particle_num=P, seed=seed)
+    single.setIterationNum(iters)
+    single.setReferenceCloud(model)
+    single.setTrans(scene.initial_trans())
+    phs = [HipPhases(P, r, world, dev, seed=seed, iteration_num=iters) for r in range(world)]
+    for ph in phs:
+        ph.set_reference(model)
+        ph.set_trans(scene.initial_trans())
+    for f in range(frames):
+        cloud = cached_scene("voxel", int(rng.choice([3000, 20000, 50000]))) if rng.random() < 0.6 else cached_scene("organized", 160 * 120)
+        single.setInputCloud(cloud)
+        single.compute()
+        want = single.getResult().tobytes()
+        for ph in phs:
+            ph.set_input(cloud)
+            ph.begin_frame()
+        for it in range(iters):
+            for ph in phs:
+                ph.phase_a(it)
+            bb = torch.stack([ph.bbox6 for ph in phs]).max(0).values
+            for ph in phs:
+                ph.bbox6.copy_(bb)
+                ph.phase_b()
+            g = torch.cat([ph.shard for ph in phs])
+            for ph in phs:
+                ph.gathered.copy_(g)
+                ph.phase_c()
+        for r, ph in enumerate(phs):
+            assert ph.get_result().tobytes() == want, (f, r)
+    want_p = single.getParticles().view(np.float32).reshape(-1, 8)
+    for r, ph in enumerate(phs):
+        np.testing.assert_array_equal(ph.get_particles().view(np.float32).reshape(-1, 8).view(np.uint32), want_p.view(np.uint32), err_msg="rank %d" % r)
+    return dict(LAST), "shard"
+
+
+def exact_case(rng, env):
+    """NearestPairPointCloudCoherence (pft_config.exact_nearest): the true nearest neighbour inside the gate -- index and
+    float squared distance of every in-gate pair equal the oracle's exhaustive search, outside the gate no neighbour;
+    search path (cell-sorted lists / per-query lists / shells only) drawn at random"""
+    path = rng.choice(["", "PFT_EXACT_PER_QUERY", "PFT_EXACT_SHELLS_ONLY"])
+    for k in ("PFT_EXACT_PER_QUERY", "PFT_EXACT_SHELLS_ONLY"):
+        os.environ.pop(k, None)
+    if path:
+        os.environ[str(path)] = "1"
+    kind, cloud = random_cloud(rng)
+    if len(cloud) > 20000:
+        cloud = cloud[:20000]
+    M = int(rng.choice([1, 7, 64, 200, 513]))
+    model = scene.make_model(M, seed=int(rng.integers(1, 1000)))
+    P = int(rng.choice([1, 16, 48]))
+    maxd = float(rng.choice([0.05, 0.1, 0.25]))
+    c = cloud_centre(cloud, kind)
+    pose = (c[0], c[1], c[2]) + tuple(scene.model_gt_pose()[3:])
+    sig_t, sig_r = float(rng.choice([0.0, 0.015, 0.1])), float(rng.choice([0.0, 0.09, 1.0]))
+    LAST.clear()
+    LAST.update(dict(exact=str(path), kind=str(kind), N=len(cloud), M=M, P=P, maxd=maxd, sig_t=sig_t, sig_r=sig_r))
+    try:
+        o = orc.Tracker(orc.default_config(particle_num=P, threads=0, emulate_pcl_alloc=0, exact_nearest=1, max_distance=maxd))
+        g = tracker.ParticleFilterTracker(seed=1)
+        g.setParticleNum(P)
+        coh = tracker.NearestPairPointCloudCoherence()
+        coh.addPointCoherence(tracker.DistanceCoherence())
+        hc = tracker.HSVColorCoherence()
+        hc.setWeight(0.1)
+        coh.addPointCoherence(hc)
+        coh.setSearchMethod(tracker.OctreeSearch(0.01))
+        coh.setMaximumDistance(maxd)
+        g.setCloudCoherence(coh)
+        for ref, tr, inp in ((g.setReferenceCloud, g.setTrans, g.setInputCloud), (o.set_reference, o.set_trans, o.set_input)):
+            ref(model)
+            tr(scene.initial_trans())
+            inp(cloud)
+        p = TP.particles_around(pose, P, int(rng.integers(1, 1 << 30)), sig_t, sig_r)
+        G = g.evalWeights(p, want_nn=True)
+        O = o.eval_weights(p, want_nn=True, mats=g.debugPoseToMatrix(p))
+        np.testing.assert_array_equal(G["crop_idx"], O["crop_idx"])
+        if len(O["crop_idx"]) == 0:
+            assert (G["raw"] == 0).all()
+            return dict(LAST), "exact-empty"
+        gate = O["nn_d2"].astype(np.float64) < maxd * maxd
+        np.testing.assert_array_equal(G["nn_idx"][gate], O["nn_idx"][gate])
+        np.testing.assert_array_equal(G["nn_d2"][gate].view(np.uint32), O["nn_d2"][gate].view(np.uint32))
+        assert (G["nn_idx"][~gate] == -1).all()
+        assert TP.ulp_diff(G["raw"], O["raw"]).max() <= 1
+    finally:
+        for k in ("PFT_EXACT_PER_QUERY", "PFT_EXACT_SHELLS_ONLY"):
+            os.environ.pop(k, None)
+    return dict(LAST), "exact"
+
+
 def run_case(cseed):
     crng = np.random.default_rng(cseed)
     env = {}
@@ -190,8 +364,9 @@ def run_case(cseed):
         if k.startswith("FUZZ_"):
             os.environ[k[5:]] = v
             env[k[5:]] = v
-    kind = "track" if crng.random() < 0.25 else "eval"
-    return kind, env, (track_case if kind == "track" else eval_case)(crng, env)
+    u = crng.random()
+    kind = "track" if u < 0.20 else ("filter" if u < 0.32 else ("shard" if u < 0.40 else ("exact" if u < 0.48 else "eval")))
+    return kind, env, {"track": track_case, "filter": filter_case, "eval": eval_case, "shard": shard_case, "exact": exact_case}[kind](crng, env)
 
 
 def main():
@@ -203,7 +378,7 @@ def main():
         return 0
     rng = np.random.default_rng(seed0)
     t_end = time.time() + minutes * 60.0
-    n = {"eval": 0, "track": 0}
+    n = {"eval": 0, "track": 0, "filter": 0, "shard": 0, "exact": 0}
     failed = []
     notes = {}
     t0 = time.time()
@@ -221,9 +396,8 @@ def main():
             print("FAILED %s case seed %d env %s: %s\n   case: %s" % (kind, cseed, env, repr(e)[:500], LAST), flush=True)
             traceback.print_exc(limit=2)
         if case % 25 == 0:
-            print("%5d cases in %.0f s (eval %d, track %d), failures %d" % (case, time.time() - t0, n["eval"], n["track"], len(failed)), flush=True)
-    print("campaign seed %d: %d eval cases, %d track cases in %.1f min; outcomes %s; FAILURES: %d" % (
-        seed0, n["eval"], n["track"], (time.time() - t0) / 60.0, notes, len(failed)))
+            print("%5d cases in %.0f s (%s), failures %d" % (case, time.time() - t0, n, len(failed)), flush=True)
+    print("campaign seed %d: %s cases in %.1f min; outcomes %s; FAILURES: %d" % (seed0, n, (time.time() - t0) / 60.0, notes, len(failed)))
     for f in failed:
         print("   ", f)
     return 1 if failed else 0
