@@ -74,6 +74,7 @@ struct pft_tracker {
   uint32_t *d_eg_start = nullptr, *d_eg_cnt = nullptr, *d_eg_tile = nullptr;
   uint32_t *d_ec_slot = nullptr, *d_ec_cells = nullptr, *d_ec_count = nullptr, *d_ec_base = nullptr;
   float4* d_ec_list = nullptr;
+  uint32_t ec_pool_cap = 0;  // entries of d_ec_list
   // exact-NN mode, cell-sorted queries (sized by the largest particle count x reference size evaluated so far)
   uint32_t *d_eq_cellq = nullptr, *d_eq_nq = nullptr, *d_eq_qbase = nullptr, *d_eq_bbase = nullptr, *d_eq_fill = nullptr,
            *d_eq_blk = nullptr, *d_eq_tiles = nullptr;
@@ -356,6 +357,7 @@ static void sync_dev(pft_tracker* t) {
   d.ec_count = t->d_ec_count;
   d.ec_base = t->d_ec_base;
   d.ec_list = t->d_ec_list;
+  d.ec_pool_cap = t->ec_pool_cap;
   d.eq_cellq = t->d_eq_cellq;
   d.eq_nq = t->d_eq_nq;
   d.eq_qbase = t->d_eq_qbase;
@@ -543,7 +545,8 @@ extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
     A(dalloc(&t->d_ec_cells, (size_t)PFT_EC_SLOTS));
     A(dalloc(&t->d_ec_count, (size_t)PFT_EC_SLOTS));
     A(dalloc(&t->d_ec_base, (size_t)PFT_EC_SLOTS));
-    A(dalloc(&t->d_ec_list, (size_t)PFT_EC_POOL));
+    t->ec_pool_cap = PFT_EC_POOL_MIN;
+    A(dalloc(&t->d_ec_list, (size_t)t->ec_pool_cap));
     A(dalloc(&t->d_eq_cellq, (size_t)PFT_EG_CAP));
     A(dalloc(&t->d_eq_nq, (size_t)PFT_EC_SLOTS));
     A(dalloc(&t->d_eq_qbase, (size_t)PFT_EC_SLOTS));
@@ -554,8 +557,8 @@ extern "C" int pft_create(const pft_config* cfg, pft_tracker** out) {
     A(dalloc(&t->d_kld_table, (size_t)6 * p.kld_max + 128));
     A(dalloc(&t->d_kld_bins, (size_t)6 * p.kld_max));
   }
-  A(hipHostMalloc(reinterpret_cast<void**>(&t->h_stat), 4 * sizeof(uint32_t), hipHostMallocMapped));
-  if (t->h_stat) t->h_stat[0] = t->h_stat[1] = t->h_stat[2] = t->h_stat[3] = 0;
+  A(hipHostMalloc(reinterpret_cast<void**>(&t->h_stat), 8 * sizeof(uint32_t), hipHostMallocMapped));
+  if (t->h_stat) for (int i = 0; i < 8; i++) t->h_stat[i] = 0;  // [0..3]: pft_debug_get_host_stat; [4]: exact-NN pool demand
   {
     const char* fb = getenv("PFT_FORCE_BUILDER");
     t->force_builder = fb ? (!strcmp(fb, "single") ? 1 : (!strcmp(fb, "sorted") ? 2 : 0)) : 0;
@@ -858,6 +861,30 @@ static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32
           dfree(t->d_eq_sorted); dfree(t->d_eq_out); dfree(t->d_eq_blk);
         }
       }
+      // the candidate pool follows the demand of the previous iteration (pinned status word 4, read without
+      // synchronising; a pool that is too small costs time -- its overflow cells keep the ring search -- never the result)
+      {
+        const volatile uint32_t* hs = t->h_stat;
+        const uint32_t demand = hs ? hs[4] : 0u;
+        if (demand > t->ec_pool_cap && t->ec_pool_cap < PFT_EC_POOL) {
+          unsigned long long want = (unsigned long long)demand + demand / 4u;  // a quarter of head-room
+          uint32_t cap = t->ec_pool_cap;
+          while (cap < want && cap < PFT_EC_POOL) cap <<= 1;
+          hipStreamSynchronize(t->stream);
+          float4* grown = nullptr;
+          if (dalloc(&grown, (size_t)cap) == hipSuccess) {
+            dfree(t->d_ec_list);
+            t->d_ec_list = grown;
+            t->ec_pool_cap = cap;
+          } else {
+            (void)hipGetLastError();  // keep the smaller pool
+          }
+        }
+        dq.ec_list = t->d_ec_list;
+        dq.ec_pool_cap = t->ec_pool_cap;
+        t->dev.ec_list = t->d_ec_list;
+        t->dev.ec_pool_cap = t->ec_pool_cap;
+      }
       dq.eq_sorted = t->d_eq_sorted;
       dq.eq_out = t->d_eq_out;
       dq.eq_blk = t->d_eq_blk;
@@ -868,7 +895,7 @@ static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32
     }
     {
       ProfScope ps(t, PFT_K_OCTREE);
-      pftk_exact_grid(t->stream, t->prm, d);
+      pftk_exact_grid(t->stream, t->prm, dq);  // (dq: the copy that carries the current candidate pool)
     }
     ProfScope ps(t, PFT_K_LIKELIHOOD);
     pftk_likelihood_exact(t->stream, t->prm, dq, np, debug_nn, t->num_cus);

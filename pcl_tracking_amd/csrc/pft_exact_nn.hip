@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256) void k_ec_build(PftParams prm, PftDev d) {
         base = (uint32_t)__shfl((int)base, 0);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (base + total > PFT_EC_POOL || base + total < base) {  // (wave-uniform) the pool is full: no list for this cell
+        if (base + total > d.ec_pool_cap || base + total < base) {  // (wave-uniform) the pool is full: no list for this cell
           total = EC_NOLIST;
           break;
         }
@@ -638,6 +638,9 @@ __global__ __launch_bounds__(256) void k_likelihood_exact(PftParams prm, PftDev 
     lut_s[i] = (float)i / 255.0f;
   }
   __syncthreads();
+  // the candidate pool follows the demand: entries asked for in this iteration (may exceed the capacity: the cells that
+  // found it full kept the ring search), read by the host without synchronising before the next iteration
+  if (blockIdx.x == 0 && threadIdx.x == 0 && d.host_stat) d.host_stat[4] = h->ec_pool_used;
   if (h->error && blockIdx.x == 0 && threadIdx.x == 0 && d.host_stat) {  // as k_likelihood: surfaced at the next host sync
     d.host_stat[2] = h->error;
     d.host_stat[3] |= h->error;
@@ -958,6 +961,9 @@ __global__ __launch_bounds__(256) void k_eq_search(PftParams prm, PftDev d) {
 __global__ __launch_bounds__(256) void k_eq_reduce(PftParams prm, PftDev d, uint32_t n_particles) {
   const PftHeader* h = d.hdr;
   if (d.p_active) n_particles = *d.p_active;
+  // the candidate pool follows the demand: entries asked for in this iteration (may exceed the capacity: the cells that
+  // found it full kept the ring search), read by the host without synchronising before the next iteration
+  if (blockIdx.x == 0 && threadIdx.x == 0 && d.host_stat) d.host_stat[4] = h->ec_pool_used;
   if (h->error && blockIdx.x == 0 && threadIdx.x == 0 && d.host_stat) {  // as k_likelihood: surfaced at the next host sync
     d.host_stat[2] = h->error;
     d.host_stat[3] |= h->error;

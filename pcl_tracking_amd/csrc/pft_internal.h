@@ -46,7 +46,8 @@
 #define PFT_SORTED_BUILD_MIN 18000  // cropped points (last iteration) above which the sorted builder is used
 #define PFT_EG_CAP (1u << 21)     // exact-NN mode: grid cells (8 MB of cell starts)
 #define PFT_EC_SLOTS (1u << 19)  // exact-NN mode: candidate lists per iteration (cells hit by queries)
-#define PFT_EC_POOL (1u << 24)   // exact-NN mode: candidate entries of all lists together (16 B each)
+#define PFT_EC_POOL (1u << 24)   // exact-NN mode: candidate entries of all lists together (16 B each), upper limit
+#define PFT_EC_POOL_MIN (1u << 20)  // first allocation (16 MB); the pool then follows the demand of the previous iteration
 #define PFT_POPM_THREADS 256
 #define PFT_POPM_ITEMS 16   // many-workgroup population path: 4096 particles per workgroup
 #define PFT_POPM_MAX_WGS 256
@@ -170,7 +171,8 @@ struct PftDev {  // device pointers (host-side struct, passed by value)
   uint32_t* ec_cells;        // exact-NN mode: [PFT_EC_SLOTS] cell of every list slot
   uint32_t* ec_count;        // exact-NN mode: [PFT_EC_SLOTS] candidates of the list (0xffffffff: the pool was full, no list)
   uint32_t* ec_base;         // exact-NN mode: [PFT_EC_SLOTS] first entry of the list in ec_list
-  float4* ec_list;           // exact-NN mode: [PFT_EC_POOL] candidates {x, y, z, position in leaf_pts}
+  float4* ec_list;           // exact-NN mode: [ec_pool_cap] candidates {x, y, z, position in leaf_pts}
+  uint32_t ec_pool_cap;      // entries of ec_list: grows with the demand of the previous iteration, at most PFT_EC_POOL
   // exact-NN mode, queries sorted by grid cell (one wave then walks ONE candidate list for 64 queries):
   uint32_t* eq_cellq;        // [eg_cap] queries per grid cell this iteration
   uint32_t* eq_nq;           // [PFT_EC_SLOTS] queries of the slot's cell that are searched through its list
