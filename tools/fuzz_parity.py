@@ -36,8 +36,6 @@ from pcl_tracking_amd import filters, scene, tracker  # noqa: E402
 import test_gpu_parity as TP  # noqa: E402
 
 KEYS = ("x", "y", "z", "roll", "pitch", "yaw")
-minutes = float(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1] != "--case" else 10.0
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[1] != "--case" else 1
 _scene_cache = {}
 LAST = {}  # description of the case being run (printed when it fails)
 
@@ -54,7 +52,7 @@ def random_cloud(rng):
     if kind == "voxel":
         c = cached_scene("voxel", int(rng.choice([3000, 20000, 50000])))
     elif kind == "organized":
-        w = int(rng.choice([80, 160, 320]))
+        w = int(rng.choice([80, 160, 320, 320, 640]))  # 640 x 480: BASELINE configs[2]'s cloud, crops of 100 000 points and more
         c = cached_scene("organized", w * (w * 3 // 4))
     else:
         n = int(rng.integers(1, 30000))
@@ -107,10 +105,40 @@ def eval_case(rng, env):
     sig_r = float(rng.choice([0.0, 0.05, 0.09, 1.0]))
     if rng.random() < 0.05:  # far outside the cloud: empty crop
         pose = (pose[0] + 30.0,) + pose[1:]
-    desc = dict(kind=kind, N=len(cloud), M=len(model), P=P, sig_t=sig_t, sig_r=sig_r, pose=[round(float(v), 4) for v in pose], env=dict(env))
+    params = {}
+    if rng.random() < 0.4:  # everything a caller of the PCL classes can set (tests/test_gpu_parity.py: non-default parameters)
+        params = dict(octree_resolution=float(rng.choice([0.003, 0.005, 0.01, 0.02, 0.037, 0.1])),
+                      max_distance=float(rng.choice([0.01, 0.05, 0.1, 0.3])),
+                      distance_weight=float(rng.choice([1.0, 4.0])), hsv_weight=float(rng.choice([0.0, 0.1, 1.5])),
+                      h_weight=float(rng.choice([1.0, 0.5])), s_weight=float(rng.choice([1.0, 2.0])),
+                      v_weight=float(rng.choice([0.0, 1.0])), hsv_pcl180_argorder=int(rng.integers(0, 2)))
+    desc = dict(kind=kind, N=len(cloud), M=len(model), P=P, sig_t=sig_t, sig_r=sig_r, pose=[round(float(v), 4) for v in pose], env=dict(env),
+                params=params)
     LAST.clear()
     LAST.update(desc)
-    g, o = TP.make_pair(tracker, orc, model, cloud, P)
+    if params:
+        o = orc.Tracker(orc.default_config(particle_num=P, threads=0, emulate_pcl_alloc=0, **params))
+        g = tracker.ParticleFilterTracker(seed=1)
+        g.setParticleNum(P)
+        coh = tracker.ApproxNearestPairPointCloudCoherence()
+        dc, hc = tracker.DistanceCoherence(), tracker.HSVColorCoherence()
+        dc.setWeight(params["distance_weight"])
+        hc.setWeight(params["hsv_weight"])
+        hc.setHWeight(params["h_weight"])
+        hc.setSWeight(params["s_weight"])
+        hc.setVWeight(params["v_weight"])
+        coh.addPointCoherence(dc)
+        coh.addPointCoherence(hc)
+        coh.setSearchMethod(tracker.OctreeSearch(params["octree_resolution"]))
+        coh.setMaximumDistance(params["max_distance"])
+        g.setCloudCoherence(coh)
+        g._cfg.hsv_pcl180_argorder = params["hsv_pcl180_argorder"]
+        for ref, tr, inp in ((g.setReferenceCloud, g.setTrans, g.setInputCloud), (o.set_reference, o.set_trans, o.set_input)):
+            ref(model)
+            tr(scene.initial_trans())
+            inp(cloud)
+    else:
+        g, o = TP.make_pair(tracker, orc, model, cloud, P)
     p = TP.particles_around(pose, P, int(rng.integers(1, 1 << 30)), sig_t, sig_r)
     mats = g.debugPoseToMatrix(p)
     G = g.evalWeights(p, want_nn=True)
@@ -125,7 +153,7 @@ def eval_case(rng, env):
     assert G["octree_depth"] == O["octree_depth"], (G["octree_depth"], O["octree_depth"])
     np.testing.assert_array_equal(G["octree_min"], O["octree_min"])
     np.testing.assert_array_equal(G["octree_max"], O["octree_max"])
-    ot = orc.Octree(np.ascontiguousarray(cloud)[O["crop_idx"]])
+    ot = orc.Octree(np.ascontiguousarray(cloud)[O["crop_idx"]], resolution=params.get("octree_resolution", 0.01))
     if len(O["crop_idx"]) <= 20000:  # (orc_octree_point_key is a Python-side loop)
         np.testing.assert_array_equal(G["point_keys"], ot.point_keys())
     assert G["n_leaves"] == ot.info()["leaves"]
@@ -369,6 +397,32 @@ def run_case(cseed):
     return kind, env, {"track": track_case, "filter": filter_case, "eval": eval_case, "shard": shard_case, "exact": exact_case}[kind](crng, env)
 
 
+def campaign(minutes, seed, max_cases=None, verbose=True):
+    """runs cases until the time budget or the case count is used up; returns (counts per kind, failures)"""
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + minutes * 60.0
+    n = {"eval": 0, "track": 0, "filter": 0, "shard": 0, "exact": 0}
+    failed = []
+    t0 = time.time()
+    case = 0
+    while time.time() < t_end and (max_cases is None or case < max_cases):
+        case += 1
+        cseed = int(rng.integers(1, 1 << 62))
+        kind, env = "?", {}
+        try:
+            kind, env, (desc, note) = run_case(cseed)
+            n[kind] += 1
+        except Exception as e:  # noqa: BLE001  (the campaign goes on; the case is reported with its seed)
+            failed.append((kind, cseed, repr(e)[:300], dict(LAST)))
+            if verbose:
+                print("FAILED case seed %d env %s: %s\n   case: %s" % (cseed, env, repr(e)[:500], LAST), flush=True)
+        if verbose and case % 25 == 0:
+            print("%5d cases in %.0f s (%s), failures %d" % (case, time.time() - t0, n, len(failed)), flush=True)
+    for k in ("PFT_FORCE_BUILDER", "PFT_LEAF_INDIRECT", "PFT_GENERIC_DESCENT"):
+        os.environ.pop(k, None)
+    return n, failed
+
+
 def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--case":  # python tools/fuzz_parity.py --case SEED: one case, verbosely
         try:
@@ -376,28 +430,11 @@ def main():
         finally:
             print("case:", LAST)
         return 0
-    rng = np.random.default_rng(seed0)
-    t_end = time.time() + minutes * 60.0
-    n = {"eval": 0, "track": 0, "filter": 0, "shard": 0, "exact": 0}
-    failed = []
-    notes = {}
+    minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 10.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     t0 = time.time()
-    case = 0
-    while time.time() < t_end:
-        case += 1
-        cseed = int(rng.integers(1, 1 << 62))
-        kind, env = "?", {}
-        try:
-            kind, env, (desc, note) = run_case(cseed)
-            n[kind] += 1
-            notes[note.split(" ")[0]] = notes.get(note.split(" ")[0], 0) + 1
-        except Exception as e:  # noqa: BLE001  (the campaign goes on; the case is reported with its seed)
-            failed.append((kind, cseed, repr(e)[:300]))
-            print("FAILED %s case seed %d env %s: %s\n   case: %s" % (kind, cseed, env, repr(e)[:500], LAST), flush=True)
-            traceback.print_exc(limit=2)
-        if case % 25 == 0:
-            print("%5d cases in %.0f s (%s), failures %d" % (case, time.time() - t0, n, len(failed)), flush=True)
-    print("campaign seed %d: %s cases in %.1f min; outcomes %s; FAILURES: %d" % (seed0, n, (time.time() - t0) / 60.0, notes, len(failed)))
+    n, failed = campaign(minutes, seed0)
+    print("campaign seed %d: %s cases in %.1f min; FAILURES: %d" % (seed0, n, (time.time() - t0) / 60.0, len(failed)))
     for f in failed:
         print("   ", f)
     return 1 if failed else 0
