@@ -327,7 +327,7 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         node = base + __popc(mask & ((1u << bc) - 1u));
         // U10 (switch point): the path key follows the chosen (minimum) child, PCL's `minChildKey`;
         // the upstream variant that handed down `new_key` -- the last existing child iterated -- would take the bits of
-        // 31 - clz(mask) here instead of bc (oracle: pft_oracle.c, orc_octree_approx_nearest)
+        // 31 - clz(mask) here instead of bc (the CPU restatement under oracle/ carries the same note)
         jx = 2u * jx + ((bc >> 2) & 1u);
         jy = 2u * jy + ((bc >> 1) & 1u);
         jz = 2u * jz + (bc & 1u);
