@@ -48,24 +48,25 @@ POSE3 = (0.05, -0.05, 0.9, 0.65, -0.55, 0.7)  # the box corner-on: faces -x, -y,
 _cache = {}
 
 
-def model3():
-    if "model" not in _cache:
+def model3(M=1024):
+    """the model (points, centroid offset); M model points: the CPU oracle is what this test waits for (8 seeds x 32 frames,
+    cost proportional to particles x model points), so the 8 192-particle case takes 512 points, the others 1 024"""
+    if ("model", M) not in _cache:
         assert len(scene._visible_faces(scene.MODEL_DIMS, POSE3)) == 3
-        # 1 024 model points: the CPU oracle is what this test waits for (8 seeds x 32 frames x 8 192 particles)
-        _cache["model"] = scene.make_model(1024, view_pose=POSE3, return_offset=True)
-    return _cache["model"]
+        _cache[("model", M)] = scene.make_model(M, view_pose=POSE3, return_offset=True)
+    return _cache[("model", M)]
 
 
-def gt_pose(f):
+def gt_pose(f, M=1024):
     """pose the tracker should estimate at frame f for the re-centred model"""
     pose = scene.advance_pose(POSE3, f)
     T = scene.pose_matrix(*pose)
-    t = T[:3, :3] @ model3()[1] + T[:3, 3]
+    t = T[:3, :3] @ model3(M)[1] + T[:3, 3]
     return (t[0], t[1], t[2], pose[3], pose[4], pose[5])
 
 
-def initial_trans3():
-    g = gt_pose(0)
+def initial_trans3(M=1024):
+    g = gt_pose(0, M)
     m = np.eye(4, dtype=np.float32)
     m[:3, 3] = (g[0] + 0.01, g[1] + 0.01, g[2] + 0.01)
     return m
@@ -84,9 +85,9 @@ def frame_cloud(f):
     return _cache[("cloud", f)]
 
 
-def pose_error(r, f):
+def pose_error(r, f, M=1024):
     """(translation distance [m], rotation angle [rad]) between a result pose and the frame's ground truth"""
-    gt = gt_pose(f)
+    gt = gt_pose(f, M)
     A = scene.pose_matrix(*[float(r[k]) for k in KEYS])
     B = scene.pose_matrix(*gt)
     R = A[:3, :3].T @ B[:3, :3]
@@ -109,7 +110,8 @@ def gpu():
 
 @pytest.mark.parametrize("P,kld", [(8192, False), (400, False), (400, True)])
 def test_device_and_pcl_arithmetic_are_the_same_filter_in_distribution(gpu, orc, P, kld, record_property):
-    model = model3()[0]
+    M = 512 if P >= 8192 else 1024
+    model = model3(M)[0]
     S = len(SEEDS)
     err_g = np.zeros((S, FRAMES, 2))
     err_o = np.zeros((S, FRAMES, 2))
@@ -121,7 +123,7 @@ def test_device_and_pcl_arithmetic_are_the_same_filter_in_distribution(gpu, orc,
                                            kld_adaptive=1 if kld else 0))  # default modes: PCL's cosf / sinf and sums
         for ref, tr in ((g.setReferenceCloud, g.setTrans), (o.set_reference, o.set_trans)):
             ref(model)
-            tr(initial_trans3())
+            tr(initial_trans3(M))
         bad, worst_before = None, 0.0
         for f in range(FRAMES):
             cloud = frame_cloud(f)
@@ -132,8 +134,8 @@ def test_device_and_pcl_arithmetic_are_the_same_filter_in_distribution(gpu, orc,
             rg, ro = g.getResult(), o.get_result()
             assert all(np.isfinite(float(rg[k])) for k in KEYS)
             res_g[si][f], res_o[si][f] = rg.copy(), ro.copy()
-            err_g[si, f] = pose_error(rg, f)
-            err_o[si, f] = pose_error(ro, f)
+            err_g[si, f] = pose_error(rg, f, M)
+            err_o[si, f] = pose_error(ro, f, M)
             a = max(abs(float(rg[k]) - float(ro[k])) for k in KEYS)
             if a >= 1e-4 and bad is None:
                 bad = f
