@@ -1272,7 +1272,11 @@ extern "C" int pft_eval_weights(pft_tracker* t, const pft_particle* particles, s
   int r = check_ready(t);
   if (r != PFT_OK) return r;
   if (!particles || !P) return PFT_ERR_INVALID_ARG;
-  if (P > (t->prm.kld ? t->Pcap : t->prm.P_local)) return PFT_ERR_CAPACITY;
+  if (P > (t->prm.kld ? t->Pcap : t->prm.P_local)) {
+    t->err = "pft_eval_weights: " + std::to_string(P) + " particles handed over, the handle's buffers hold " +
+             std::to_string(t->prm.kld ? t->Pcap : t->prm.P_local) + " (particle_num / maximum_particle_num of this rank)";
+    return PFT_ERR_CAPACITY;
+  }
   r = ensure_dbg_part(t, P);
   if (r != PFT_OK) return r;
   r = ensure_dbg_f(t, P);

@@ -548,8 +548,16 @@ __global__ void k_finalize_raw(const double* __restrict__ partial, uint32_t nchu
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (p_active) n = *p_active;  // KLD variant: particle_num_ lives on the device
   if (i >= n) return;
-  double v = 0.0;
-  for (uint32_t c = 0; c < nchunk; c++) v += partial[(size_t)i * nchunk + c];
+  double v = 0.0;  // (loads eight at a time, additions in chunk order: as k_population)
+  const double* row = partial + (size_t)i * nchunk;
+  for (uint32_t c0 = 0; c0 < nchunk; c0 += 8u) {
+    double tv[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; k++) tv[k] = row[min(c0 + k, nchunk - 1u)];
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; k++)
+      if (c0 + k < nchunk) v += tv[k];
+  }
   float w = -(float)v;
   part[i].weight = w;
   if (raw_out) raw_out[i] = w;

@@ -194,6 +194,13 @@ def track_case(rng, env):
             cloud = cached_scene("organized", w * (w * 3 // 4))
         g.setInputCloud(cloud)
         o.set_input(cloud)
+        if f > 0 and rng.random() < 0.25:
+            # a weight evaluation between two frames (device only) must leave the running filter alone: it builds its own
+            # crop and octree with its own particles, through the same buffers and builder hints
+            pe = TP.particles_around(scene.model_gt_pose(), min(P, int(rng.choice([1, 33, 300]))), int(rng.integers(1, 1 << 30)),
+                                     float(rng.choice([0.015, 0.3])), float(rng.choice([0.09, 1.0])))
+            g.evalWeights(pe, want_nn=bool(rng.random() < 0.5))
+            LAST["eval_between"] = LAST.get("eval_between", 0) + 1
         g.compute()
         assert o.compute() == 0
         rg, ro = g.getResult(), o.get_result()
