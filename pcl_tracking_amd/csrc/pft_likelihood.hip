@@ -736,6 +736,8 @@ void pftk_likelihood(hipStream_t s, const PftParams& p, const PftDev& d, uint32_
   uint32_t need = (items + (PFT_LIK_THREADS / 64) - 1) / (PFT_LIK_THREADS / 64);
   if (need == 0) need = 1;
   if (grid > need) grid = need;
+  // (fewer workgroups at small particle counts -- less staging traffic -- was measured: 400 particles 52.2 us per frame with
+  // the full grid, 54.9 / 56.2 / 84.2 with 384 / 256 / 128 workgroups)
   if (debug_nn)
     hipLaunchKernelGGL(k_likelihood<true>, dim3(grid), dim3(PFT_LIK_THREADS), lds, s, p, d, n_particles, lds,
                        g_allow_fast);
