@@ -901,6 +901,7 @@ static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32
     pftk_likelihood_exact(t->stream, t->prm, dq, np, debug_nn, t->num_cus);
     return;
   }
+  bool leaf_indirect = false;  // (the sorted builder and the rescue launch behind it always write the leaf records)
   {
     ProfScope ps(t, PFT_K_OCTREE);
     PftDev db = d;
@@ -934,11 +935,11 @@ static void stage_crop_octree_likelihood(pft_tracker* t, const PftDev& d, uint32
       // leaf records followed through leaf_order by the likelihood kernel instead of being copied: +0.32 ps per query
       // there (5.4 us at 8 192 x 2 048), -3 us per build and one launch less here: pays below ~9 million queries (the
       // reference's own 400-500 particles: 0.202 -> 0.196 ms per frame)
-      pftk_octree(t->stream, t->prm, db, last_n, (unsigned long long)np * t->prm.M <= 8000000ull);
+      leaf_indirect = pftk_octree(t->stream, t->prm, db, last_n, (unsigned long long)np * t->prm.M <= 8000000ull);
   }
   {
     ProfScope ps(t, PFT_K_LIKELIHOOD);
-    pftk_likelihood(t->stream, t->prm, d, np, debug_nn, t->num_cus);
+    pftk_likelihood(t->stream, t->prm, d, np, debug_nn, t->num_cus, leaf_indirect);
   }
 }
 

@@ -222,7 +222,8 @@ void pftk_resample_kld(hipStream_t s, const PftParams& p, const PftDev& d, uint3
 // raw: the input in PCL's 32-byte layout when its 16-byte records have not been formed yet (first crop of a frame), else null
 void pftk_crop(hipStream_t s, const PftParams& p, const PftDev& d, bool bbox_from_partials, uint32_t epoch,
                const pft_point_xyzrgba* raw);
-void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t expected_points, bool allow_indirect = true);
+// returns true when the leaf records were left for the likelihood kernel to follow through leaf_order (its INDIRECT form)
+bool pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t expected_points, bool allow_indirect = true);
 // no-op launch unless the sorted builder flagged "radix passes too few" (error bit 3): then the single-workgroup build
 void pftk_octree_rescue(hipStream_t s, const PftParams& p, const PftDev& d);
 struct SortBufs {
@@ -237,7 +238,7 @@ struct SortBufs {
 void pftk_octree_sorted(hipStream_t s, const PftParams& p, const PftDev& d, const SortBufs& sb, uint32_t n_pad,
                         int npass);
 void pftk_likelihood(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, bool debug_nn,
-                     int num_cus);
+                     int num_cus, bool leaf_indirect = false);
 // shard (nullable): sharded handles -- the particles with their raw weights also go into the all-gather's send buffer
 void pftk_finalize_raw(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles,
                        float* raw_out /*nullable*/, pft_particle* shard /*nullable*/);

@@ -21,23 +21,14 @@
 // "fast descent"); otherwise the level is evaluated generically.  Results are bit-identical to the
 // all-generic descent (tests/test_gpu_parity.py compares index and distance of every pair).
 // Algorithmic bytes per pair-eval: 16 (reference point) + 16 per candidate scanned in the reached leaf.
+// (Round 3 experiments that are NOT in this file any more, because their scaffolding -- the loop bodies as lambdas, a ballot
+// per trip -- cost the product kernel 2 %: the three per-lane loops with their sparse tails padded to 12 lanes,
+// -DPFT_LIK_PAD; measured 178.8 ... 202 us against 176.8, profiles/r03_padding_variants_ab.txt; the code is in the
+// repository history, commit "Phase stamps only in the diagnostic variant ...".)
 #include "pft_device_utils.h"
 
 #ifndef PFT_LIK_PENALTY
 #define PFT_LIK_PENALTY 1
-#endif
-// lanes that run along when a per-lane loop iteration has 8 or fewer active lanes (0: no padding)
-#ifndef PFT_LIK_PAD
-#define PFT_LIK_PAD 0
-#endif
-#ifndef PFT_LIK_PAD_FAST
-#define PFT_LIK_PAD_FAST PFT_LIK_PAD
-#endif
-#ifndef PFT_LIK_PAD_GEN
-#define PFT_LIK_PAD_GEN PFT_LIK_PAD
-#endif
-#ifndef PFT_LIK_PAD_LEAF
-#define PFT_LIK_PAD_LEAF PFT_LIK_PAD
 #endif
 
 struct LikCtx {
@@ -95,11 +86,13 @@ __device__ __forceinline__ int near_face_level(uint32_t k, bool low, bool high) 
 
 // LEAF: where the leaf level's start offsets come from -- 0: the node words themselves (W), 1: u16 array in LDS,
 // 2: the u32 words in HBM / L2 (the branch levels alone are in LDS)
-template <bool USE_TAB, bool FAST, bool DEBUG_NN, int LEAF, typename WordPtr>
+// INDIRECT (PftHeader::leaf_indirect; compile-time here -- as a run-time flag the branch in the leaf scan cost 4 us per launch
+// at the headline size): the builder left the point records where the crop put them, a candidate is
+// crop_pts[leaf_order[pos]] and bpos carries the record's index in crop_pts
+template <bool USE_TAB, bool FAST, bool DEBUG_NN, int LEAF, bool INDIRECT, typename WordPtr>
 __device__ __forceinline__ void likelihood_items(const PftParams& prm, const PftDev& d, const LikCtx& cx, WordPtr W,
                                                  uint32_t n_particles, int D, uint32_t n_crop,
                                                  const double omin[3], int abl) {
-  const bool indirect = d.hdr->leaf_indirect != 0;  // (wave-uniform)
   const int lane = lane_id(), w = wave_id(), nw = blockDim.x >> 6;
   const uint32_t M = prm.M, nchunk = prm.nchunk;
   // Work distribution.  The cost of an item depends on where its queries land, and with a static round-robin the
@@ -205,41 +198,6 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         }
         // fast levels: follow the key while the child containing the query exists (a divergent loop: a version
         // with a wave-uniform trip count and predicated steps was slower, 280 us against 267)
-#if PFT_LIK_PAD_FAST
-        {  // (as the generic loop below: an iteration with 8 or fewer lanes left is kept company by lanes 0 .. PFT_LIK_PAD-1)
-          auto fast_step = [&](uint32_t& nd, int& lv) -> bool {
-            const int sh = D - lv - 1;
-            const uint32_t c = (((kx >> sh) & 1u) << 2) | (((ky >> sh) & 1u) << 1) | ((kz >> sh) & 1u);
-            const uint32_t wv = W[nd];
-            if (!((wv >> c) & 1u)) return false;
-            nd = (wv >> 8) + __popc(wv & 0xffu & ((1u << c) - 1u));
-            lv++;
-            return true;
-          };
-          bool fa = lvl < lim;
-          for (;;) {
-            const unsigned long long am = __ballot(fa);
-            if (!am) break;
-            if (__popcll(am) > 8) {
-              if (fa) {
-                fa = fast_step(node, lvl);
-                if (fa) dbg_fast++;
-                fa = fa && lvl < lim;
-              }
-            } else if (fa || lane < PFT_LIK_PAD_FAST) {
-              uint32_t n2 = fa ? node : 0u;
-              int l2 = fa ? lvl : 0;
-              const bool go = fast_step(n2, l2);
-              if (fa) {
-                node = n2;
-                lvl = l2;
-                if (go) dbg_fast++;
-                fa = go && lvl < lim;
-              }
-            }
-          }
-        }
-#else
         while (lvl < lim) {
           const int sh = D - lvl - 1;
           const uint32_t c = (((kx >> sh) & 1u) << 2) | (((ky >> sh) & 1u) << 1) | ((kz >> sh) & 1u);
@@ -249,7 +207,6 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
           lvl++;
           dbg_fast++;
         }
-#endif
         const int up = D - lvl;
         const uint32_t top = 1u << lvl;
         jx = (kx >> up) | top; jy = (ky >> up) | top; jz = (kz >> up) | top;
@@ -259,9 +216,7 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         node = cx.leaf0;
         lvl = D;
       }
-      // One generic level on (node, jx, jy, jz), as a step so that the loop below can run it for lanes that only keep the
-      // wave company (PFT_LIK_PAD).
-      auto generic_step = [&](uint32_t& node, uint32_t& jx, uint32_t& jy, uint32_t& jz, const int lvl) {
+      for (; lvl < D; lvl++) {
         dbg_gen++;
         const uint32_t wv = W[node];
         const uint32_t mask = wv & 0xffu, base = wv >> 8;
@@ -331,37 +286,7 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
         jx = 2u * jx + ((bc >> 2) & 1u);
         jy = 2u * jy + ((bc >> 1) & 1u);
         jz = 2u * jz + (bc & 1u);
-      };
-#if PFT_LIK_PAD_GEN
-      // gfx950 runs a wave64 compare / select / min / bit-field instruction in ~21 cycles instead of ~4 when 8 or fewer
-      // of its lanes are active (tools/micro/exec_mask_test.hip; plain adds are not affected), and the last iterations of
-      // this per-lane loop are exactly that: a couple of lanes with one level more to go than the rest.  Such an iteration
-      // is run with lanes 0 .. PFT_LIK_PAD-1 executing the step as well, on the root, results discarded.
-      for (;;) {
-        const bool act = lvl < D;
-        const unsigned long long am = __ballot(act);
-        if (!am) break;
-        if (__popcll(am) > 8) {  // (wave-uniform)
-          if (act) {
-            generic_step(node, jx, jy, jz, lvl);
-            lvl++;
-          }
-        } else if (act || lane < PFT_LIK_PAD_GEN) {
-          uint32_t n2 = act ? node : 0u, x2 = act ? jx : 1u, y2 = act ? jy : 1u, z2 = act ? jz : 1u;
-          const int g0 = dbg_gen, h0 = dbg_hard;
-          generic_step(n2, x2, y2, z2, act ? lvl : 0);
-          if (act) {
-            node = n2; jx = x2; jy = y2; jz = z2;
-            lvl++;
-          } else if (DEBUG_NN) {
-            dbg_gen = g0;
-            dbg_hard = h0;
-          }
-        }
       }
-#else
-      for (; lvl < D; lvl++) generic_step(node, jx, jy, jz, lvl);
-#endif
       // ---- leaf scan: first strictly-smaller wins (insertion order) ----
       uint32_t ls, le;
       if (LEAF == 1) {  // leaf starts as u16 in LDS (cropped clouds below 65536 points)
@@ -378,65 +303,48 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
       if (abl & 2) le = ls;
       float bd = (abl & 2) ? 1.0e-3f : INFINITY;
       uint32_t bpos = ls;
-      // `indirect` (wave-uniform, PftHeader::leaf_indirect): the builder left the point records where the crop put them,
-      // a candidate is crop_pts[leaf_order[pos]]; bpos then carries the record's index in crop_pts
-      auto leaf_round = [&](const uint32_t pos, const uint32_t le, float& bd, uint32_t& bpos) {  // two candidates: their gathers overlap
-        const bool two = pos + 1 < le;
-        uint32_t i1 = pos, i2 = two ? pos + 1 : pos;
-        const float4* __restrict__ rec = d.leaf_pts;
-        if (indirect) {
-          i1 = d.leaf_order[i1];
-          i2 = d.leaf_order[i2];
-          rec = d.crop_pts;
+      if (!INDIRECT) {
+        for (uint32_t pos = ls; pos < le; pos += 2) {  // two candidates per round: their gathers overlap
+          const bool two = pos + 1 < le;
+          const float4 c = d.leaf_pts[pos];
+          const float4 c2 = d.leaf_pts[two ? pos + 1 : pos];
+          float dx = c.x - qx, dy = c.y - qy, dz = c.z - qz;
+          float dd = dx * dx + (dy * dy + dz * dz);
+          bool better = dd < bd;
+          bd = better ? dd : bd;
+          bpos = better ? pos : bpos;
+          dx = c2.x - qx; dy = c2.y - qy; dz = c2.z - qz;
+          dd = dx * dx + (dy * dy + dz * dz);
+          better = two & (dd < bd);
+          bd = better ? dd : bd;
+          bpos = better ? pos + 1 : bpos;
         }
-        const float4 c = rec[i1];
-        const float4 c2 = rec[i2];
-        float dx = c.x - qx, dy = c.y - qy, dz = c.z - qz;
-        float dd = dx * dx + (dy * dy + dz * dz);
-        bool better = dd < bd;
-        bd = better ? dd : bd;
-        bpos = better ? i1 : bpos;
-        dx = c2.x - qx; dy = c2.y - qy; dz = c2.z - qz;
-        dd = dx * dx + (dy * dy + dz * dz);
-        better = two & (dd < bd);
-        bd = better ? dd : bd;
-        bpos = better ? i2 : bpos;
-      };
-#if PFT_LIK_PAD_LEAF
-      {  // (the second and later rounds belong to the few lanes whose leaf holds more than two points: padded as above)
-        uint32_t pos = ls;
-        for (;;) {
-          const bool act = pos < le;
-          const unsigned long long am = __ballot(act);
-          if (!am) break;
-          if (__popcll(am) > 8) {
-            if (act) {
-              leaf_round(pos, le, bd, bpos);
-              pos += 2;
-            }
-          } else if (act || lane < PFT_LIK_PAD_LEAF) {
-            float bd2 = bd;
-            uint32_t bp2 = bpos;
-            leaf_round(act ? pos : ls, act ? le : ls + 1u, bd2, bp2);  // (a leaf holds at least one point: ls is a valid record)
-            if (act) {
-              bd = bd2;
-              bpos = bp2;
-              pos += 2;
-            }
-          }
+      } else {
+        for (uint32_t pos = ls; pos < le; pos += 2) {
+          const bool two = pos + 1 < le;
+          const uint32_t i1 = d.leaf_order[pos], i2 = d.leaf_order[two ? pos + 1 : pos];
+          const float4 c = d.crop_pts[i1];
+          const float4 c2 = d.crop_pts[i2];
+          float dx = c.x - qx, dy = c.y - qy, dz = c.z - qz;
+          float dd = dx * dx + (dy * dy + dz * dz);
+          bool better = dd < bd;
+          bd = better ? dd : bd;
+          bpos = better ? i1 : bpos;
+          dx = c2.x - qx; dy = c2.y - qy; dz = c2.z - qz;
+          dd = dx * dx + (dy * dy + dz * dz);
+          better = two & (dd < bd);
+          bd = better ? dd : bd;
+          bpos = better ? i2 : bpos;
         }
+        // (no candidate beat +inf -- a NaN query --: bpos still holds the leaf position it started from; the direct path
+        // reports the leaf's first record then, and so does this one)
+        if (!(bd < INFINITY)) bpos = d.leaf_order[min(bpos, n_crop - 1u)];
       }
-#else
-      for (uint32_t pos = ls; pos < le; pos += 2) leaf_round(pos, le, bd, bpos);
-#endif
       // the winner's record (position + packed colour) is fetched again instead of being carried through the loop
-      // (no candidate beat +inf -- a NaN query --: bpos still holds the leaf position it started from; the direct path
-      // reports the leaf's first record then, and so does this one)
-      if (indirect && !(bd < INFINITY)) bpos = d.leaf_order[min(bpos, n_crop - 1u)];
-      const float4 bt = indirect ? d.crop_pts[bpos] : d.leaf_pts[bpos];
+      const float4 bt = INDIRECT ? d.crop_pts[bpos] : d.leaf_pts[bpos];
       if (DEBUG_NN) {
         const size_t o = (size_t)pi * M + d.ref_perm[j];
-        d.nn_idx[o] = indirect ? (int32_t)bpos : (int32_t)d.leaf_order[bpos];
+        d.nn_idx[o] = INDIRECT ? (int32_t)bpos : (int32_t)d.leaf_order[bpos];
         d.nn_d2[o] = bd;
         st_q += 1;
         st_s += le - ls;
@@ -529,7 +437,12 @@ __device__ __forceinline__ void likelihood_items(const PftParams& prm, const Pft
 #include "pft_likelihood_refill.h"
 #endif
 
-template <bool DEBUG_NN>
+// INDIRECT is a parameter of the KERNEL (the host launches the instantiation that matches the builder mode it chose:
+// pftk_octree returns it): both forms inside one kernel doubled its code and its scalar-register spills (76 -> 136) and
+// cost the headline launch 2 %
+#define PFT_LIK_RUN(UT, FA, LF) likelihood_items<UT, FA, DEBUG_NN, LF, INDIRECT>(prm, d, cx, W, n_particles, D, n_crop, omin, abl)
+
+template <bool DEBUG_NN, bool INDIRECT>
 __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * PFT_LIK_WGS_PER_CU) / 256) void k_likelihood(PftParams prm, PftDev d, uint32_t n_particles,
                                                                 uint32_t lds_bytes, int flags) {
   const int allow_fast = flags & 1;
@@ -542,7 +455,8 @@ __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * 
   const PftHeader* hdr = d.hdr;
   if (d.p_active) n_particles = *d.p_active;  // KLD variant: particle_num_ lives on the device
   const int D = hdr->depth;
-  const uint32_t n_crop = (hdr->error || D <= 0) ? 0u : hdr->n_crop;
+  // (the host launches the form the builder recorded; a mismatch would read the wrong array: no target instead)
+  const uint32_t n_crop = (hdr->error || D <= 0 || (hdr->leaf_indirect != 0) != INDIRECT) ? 0u : hdr->n_crop;
   // A failed crop / octree build leaves this launch without a target (all weights 0): the flag is mirrored into pinned
   // host memory, and the next host synchronisation point returns it to the caller (pft_get_result & co.)
   if (hdr->error && blockIdx.x == 0 && threadIdx.x == 0 && d.host_stat) {
@@ -577,7 +491,10 @@ __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * 
   const bool fits_without_jump = (size_t)used + branch_bytes + leaf_bytes <= (size_t)lds_bytes;
   // (deep trees: 24 KiB of centre tables at depth 10) the branch levels and the jump table in LDS, the leaf starts
   // from L2: 228 us against 242 us without the jump table and 238 us with the words split at an arbitrary index
-  const bool branch_only = !fits_with_jump && leaf16 && (size_t)used + jump_bytes + branch_bytes <= (size_t)lds_bytes;
+  // (only with centre tables: a tree deeper than PFT_TABLE_MAX_DEPTH has none and takes the top-levels-in-LDS layout below --
+  // found by tools/fuzz_parity.py: this layout used to read the tables regardless, and a 12-level tree over a 41 m crop box
+  // sent every query to one leaf)
+  const bool branch_only = use_tab && !fits_with_jump && leaf16 && (size_t)used + jump_bytes + branch_bytes <= (size_t)lds_bytes;
   if (!fits_with_jump && fits_without_jump && !branch_only) {
     J = 0;
     jump_bytes = 0;
@@ -647,43 +564,40 @@ __global__ __launch_bounds__(PFT_LIK_THREADS, DEBUG_NN ? 1 : (PFT_LIK_THREADS * 
   if (branch_only) {
     const uint32_t* W = lwords;
     if (fast)
-      likelihood_items<true, true, DEBUG_NN, 2>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
-    else if (use_tab)
-      likelihood_items<true, false, DEBUG_NN, 2>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
-    else  // trees deeper than PFT_TABLE_MAX_DEPTH have no centre tables (found by tools/fuzz_parity.py: this layout used to
-          // read them regardless -- a 12-level tree over a 41 m crop box sent every query to one leaf)
-      likelihood_items<false, false, DEBUG_NN, 2>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+      PFT_LIK_RUN(true, true, 2);
+    else
+      PFT_LIK_RUN(true, false, 2);
   } else if (words_in_lds && leaf16) {  // node words addressed as LDS (ds_read), not through a generic pointer
     const uint32_t* W = lwords;
     if (fast)
 #if PFT_LIK_REFILL
       likelihood_items_refill<DEBUG_NN>(prm, d, cx, W, n_particles, D, n_crop);
 #else
-      likelihood_items<true, true, DEBUG_NN, 1>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+      PFT_LIK_RUN(true, true, 1);
 #endif
     else if (use_tab)
-      likelihood_items<true, false, DEBUG_NN, 1>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+      PFT_LIK_RUN(true, false, 1);
     else
-      likelihood_items<false, false, DEBUG_NN, 1>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+      PFT_LIK_RUN(false, false, 1);
   } else if (words_in_lds) {
     const uint32_t* W = lwords;
     if (fast)
-      likelihood_items<true, true, DEBUG_NN, 0>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+      PFT_LIK_RUN(true, true, 0);
     else if (use_tab)
-      likelihood_items<true, false, DEBUG_NN, 0>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+      PFT_LIK_RUN(true, false, 0);
     else
-      likelihood_items<false, false, DEBUG_NN, 0>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+      PFT_LIK_RUN(false, false, 0);
   } else {
     HybridWords W;
     W.lds = (const __attribute__((address_space(3))) uint32_t*)lwords;
     W.glob = d.words;
     W.n_lds = n_lds_words;
     if (fast)
-      likelihood_items<true, true, DEBUG_NN, 0>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+      PFT_LIK_RUN(true, true, 0);
     else if (use_tab)
-      likelihood_items<true, false, DEBUG_NN, 0>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+      PFT_LIK_RUN(true, false, 0);
     else
-      likelihood_items<false, false, DEBUG_NN, 0>(prm, d, cx, W, n_particles, D, n_crop, omin, abl);
+      PFT_LIK_RUN(false, false, 0);
   }
 }
 
@@ -693,8 +607,8 @@ static int g_allow_fast = -1;
 extern "C" int pft_debug_likelihood_occupancy(void) {
   int nb = -1;
   uint32_t lds = ((uint32_t)pftk_max_lds_bytes() / (uint32_t)PFT_LIK_WGS_PER_CU) & ~255u;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(&k_likelihood<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_likelihood<false>), PFT_LIK_THREADS, lds) != hipSuccess) return -1;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&k_likelihood<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&k_likelihood<false, false>), PFT_LIK_THREADS, lds) != hipSuccess) return -1;
   return nb;
 }
 
@@ -708,40 +622,44 @@ extern "C" void pft_debug_set_ablate(int mask) {
 #endif
 
 void pftk_likelihood(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t n_particles, bool debug_nn,
-                     int num_cus) {
+                     int num_cus, bool leaf_indirect) {
   static bool attr_set[PFT_MAX_DEVICES];
   // half of the CU's LDS per workgroup: two 1024-thread workgroups (32 waves, 8 per SIMD) are resident per CU
   uint32_t lds = ((uint32_t)pftk_max_lds_bytes() / (uint32_t)PFT_LIK_WGS_PER_CU) & ~255u;
   const int dev = pftk_cur_device();
   if (!attr_set[dev]) {
-    const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_likelihood<false>),
+    const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_likelihood<false, false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_likelihood<true>),
+    const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_likelihood<true, false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set[dev] = e1 == hipSuccess && e2 == hipSuccess;
+    const hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_likelihood<false, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_likelihood<true, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set[dev] = e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess && e4 == hipSuccess;
   }
   {  // PFT_GENERIC_DESCENT=1: all-generic descent (A/B and parity cross-check; read per launch: tools/fuzz_parity.py draws it per case)
     const char* e = getenv("PFT_GENERIC_DESCENT");
     if (g_allow_fast < 0) g_allow_fast = 1;
     g_allow_fast = (g_allow_fast & ~1) | ((e && e[0] == '1') ? 0 : 1);
-  }
-  {
 #ifdef PFT_DIAG
     const char* a = getenv("PFT_ABLATE");  // timing experiments only: bit0 generic levels, bit1 leaf scan, bit2 coherence
     if (a) g_allow_fast |= atoi(a) << 8;
 #endif
   }
+  // (fewer workgroups at small particle counts -- less staging traffic -- was measured: 400 particles 52.2 us per frame with
+  // the full grid, 54.9 / 56.2 / 84.2 with 384 / 256 / 128 workgroups)
   uint32_t items = n_particles * p.nchunk;
   uint32_t grid = (uint32_t)PFT_LIK_WGS_PER_CU * (uint32_t)num_cus;
   uint32_t need = (items + (PFT_LIK_THREADS / 64) - 1) / (PFT_LIK_THREADS / 64);
   if (need == 0) need = 1;
   if (grid > need) grid = need;
-  // (fewer workgroups at small particle counts -- less staging traffic -- was measured: 400 particles 52.2 us per frame with
-  // the full grid, 54.9 / 56.2 / 84.2 with 384 / 256 / 128 workgroups)
-  if (debug_nn)
-    hipLaunchKernelGGL(k_likelihood<true>, dim3(grid), dim3(PFT_LIK_THREADS), lds, s, p, d, n_particles, lds,
-                       g_allow_fast);
+  if (debug_nn && leaf_indirect)
+    hipLaunchKernelGGL((k_likelihood<true, true>), dim3(grid), dim3(PFT_LIK_THREADS), lds, s, p, d, n_particles, lds, g_allow_fast);
+  else if (debug_nn)
+    hipLaunchKernelGGL((k_likelihood<true, false>), dim3(grid), dim3(PFT_LIK_THREADS), lds, s, p, d, n_particles, lds, g_allow_fast);
+  else if (leaf_indirect)
+    hipLaunchKernelGGL((k_likelihood<false, true>), dim3(grid), dim3(PFT_LIK_THREADS), lds, s, p, d, n_particles, lds, g_allow_fast);
   else
-    hipLaunchKernelGGL(k_likelihood<false>, dim3(grid), dim3(PFT_LIK_THREADS), lds, s, p, d, n_particles, lds,
-                       g_allow_fast);
+    hipLaunchKernelGGL((k_likelihood<false, false>), dim3(grid), dim3(PFT_LIK_THREADS), lds, s, p, d, n_particles, lds, g_allow_fast);
 }

@@ -722,7 +722,7 @@ static void pftk_octree_set_attr() {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
 }
 
-void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t expected_points, bool allow_indirect) {
+bool pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t expected_points, bool allow_indirect) {
   // static LDS of the kernel (BuildSh ~2.6 KB, the dense top-level arrays 5 KB): leave 10 KB out of the dynamic request
   const uint32_t lds = ((uint32_t)pftk_max_lds_bytes() - 10240u) & ~15u;
   pftk_octree_set_attr();
@@ -740,6 +740,7 @@ void pftk_octree(hipStream_t s, const PftParams& p, const PftDev& d, uint32_t ex
   // at most PFT_SORTED_BUILD_MIN-ish points reach this builder in practice, but any crop (<= N) is legal
   if (mode == 0)
     hipLaunchKernelGGL(k_leaf_gather, dim3((d.N + 255u) / 256u ? (d.N + 255u) / 256u : 1u), dim3(256), 0, s, d);
+  return indirect;
 }
 
 // behind the sorted builder: a no-op unless error bit 3 asks for the rebuild (then the whole tree, leaf records included)
