@@ -1,5 +1,5 @@
 """Randomised parity campaign on the GPU box: the HIP path through the C ABI against the CPU oracle on generated cases,
-for a time budget.  Two kinds of case:
+for a time budget.  Five kinds of case:
 
   eval   one weight evaluation (crop -> octree -> approximate nearest neighbour -> coherence) of random particles on a
          random (model, cloud) pair: bounding box, crop list, octree depth / box / per-point keys / leaf count, the
