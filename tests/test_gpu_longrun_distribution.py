@@ -50,7 +50,7 @@ _cache = {}
 
 def model3(M=1024):
     """the model (points, centroid offset); M model points: the CPU oracle is what this test waits for (8 seeds x 32 frames,
-    cost proportional to particles x model points), so the 8 192-particle case takes 512 points, the others 1 024"""
+    cost proportional to particles x model points), so the 8 192-particle case takes 384 points, the others 512"""
     if ("model", M) not in _cache:
         assert len(scene._visible_faces(scene.MODEL_DIMS, POSE3)) == 3
         _cache[("model", M)] = scene.make_model(M, view_pose=POSE3, return_offset=True)
@@ -110,7 +110,7 @@ def gpu():
 
 @pytest.mark.parametrize("P,kld", [(8192, False), (400, False), (400, True)])
 def test_device_and_pcl_arithmetic_are_the_same_filter_in_distribution(gpu, orc, P, kld, record_property):
-    M = 512 if P >= 8192 else 1024
+    M = 384 if P >= 8192 else 512
     model = model3(M)[0]
     S = len(SEEDS)
     err_g = np.zeros((S, FRAMES, 2))
