@@ -616,8 +616,11 @@ __global__ __launch_bounds__(PFT_BUILD_THREADS) void k_octree_build(PftParams pr
   __shared__ BuildSh S;
   PftHeader* hdr = d.hdr;
   if (rescue && !(hdr->error & 8u)) return;  // (uniform)
-  const uint32_t n = hdr->n_crop;
   const uint32_t tid = threadIdx.x;
+  // (issued beside the header loads, not behind them: one memory latency less at the head of this one-workgroup kernel;
+  // record 0 is valid memory whatever n_crop says)
+  const float4 p_first = tid == 0 ? d.crop_pts[0] : make_float4(0, 0, 0, 0);
+  const uint32_t n = hdr->n_crop;
 
   STAMP(0);
   if (tid == 0) {
@@ -625,7 +628,7 @@ __global__ __launch_bounds__(PFT_BUILD_THREADS) void k_octree_build(PftParams pr
     S.ngrow = 0;
     S.depth = 0;
     S.cur = 1;
-    if (n > 0) box_init(S, d.crop_pts[0], prm.res);
+    if (n > 0) box_init(S, p_first, prm.res);
   }
   __syncthreads();
 
